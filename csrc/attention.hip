@@ -1,0 +1,561 @@
+// Causal flash attention for gfx950 (MI355X): forward, dK/dV backward and dQ backward.
+//
+// Design (wave64, v_mfma_f32_32x32x16_bf16, LDS-tiled, no score matrix in memory):
+//  * Scores are computed TRANSPOSED, S^T = K * Q^T, so every lane owns one query column and
+//    the keys run along its accumulator registers: row max / row sum are in-lane reductions
+//    plus one exchange between the two 32-lane halves, and the probability tile is already in
+//    the register layout the next MFMA wants as its B operand (O^T = V^T * P^T). Nothing but
+//    K and V ever goes through LDS in the forward.
+//  * K/V (forward, dQ) and Q/dO (dK/dV) tiles are staged global -> registers -> LDS with the
+//    loads of tile t+1 issued before the compute on tile t (double-buffered LDS, one barrier
+//    per tile). One XOR-swizzled LDS image serves both the row reads (ds_read_b128, operand A
+//    of the score products) and the transposed reads (ds_read_b64_tr_b16, operand A of the
+//    products that sum over keys/queries), conflict-free for both.
+//  * GQA is native: a query head reads the K/V head of its group directly (no repeat), and
+//    the dK/dV kernel accumulates over the query heads of the group in registers.
+//  * Backward is split in two kernels so no cross-workgroup reduction (atomics) is needed:
+//    one workgroup owns 128 keys and sweeps the queries (dK, dV), the other owns 128 queries
+//    and sweeps the keys (dQ). P is recomputed from the saved log-sum-exp.
+//  * The causal mask is bottom-right aligned (query i sees keys <= i + Tk - Tq), which is what
+//    KV-cache decoding needs. Heaviest tiles are launched first.
+//
+// Replaces `F.scaled_dot_product_attention(is_causal=True)` and the `repeat_interleave` GQA
+// expansion of the reference (reference: single-gpu/model.py:144-149).
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bfrag;  // one MFMA A/B operand (8 bf16)
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ f32x16 mfma32(bfrag a, bfrag b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 16-byte-chunk swizzle of a row-major [rows][HS] bf16 LDS tile. Conflict-free for
+// ds_read_b128 row reads (lane = row) and for ds_read_b64_tr_b16 4-row block reads.
+template <int HS>
+__device__ __forceinline__ int swz(int row, int chunk) {
+  if (HS == 64) return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+  return chunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
+}
+
+// Accumulator register i of lane-half hh holds row (i&3) + 8*(i>>2) + 4*hh of a 32x32 tile.
+__device__ __forceinline__ int acc_row(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+__device__ __forceinline__ bfrag zero_frag() {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bfrag, z);
+}
+
+// Operand-A fragment by row read: lane (r, hh) gets tile[row][16*ks + 8*hh .. +7].
+template <int HS>
+__device__ __forceinline__ bfrag row_frag(const char* tile, int row, int ks, int hh) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * (HS * 2) + 16 * swz<HS>(row, 2 * ks + hh));
+  return __builtin_bit_cast(bfrag, v);
+}
+
+// Operand-A fragment by transposed read for a product that sums over the tile's ROWS:
+// lane (r, hh) gets tile[rbase + 16*s + 8*(j>>2) + 4*hh + (j&3)][32*dt + r] in element j, which
+// is the k order of an accumulator tile used as operand B.
+template <int HS>
+__device__ __forceinline__ bfrag tr_frag(const char* tile, int rbase, int s, int dt, int lane) {
+  const int hh = lane >> 5, g = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int chunk = 4 * dt + 2 * g + (pp >> 1);
+  s16x4 part[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = rbase + 16 * s + 8 * jj + 4 * hh + qq;
+    const char* a = tile + row * (HS * 2) + 16 * swz<HS>(row, chunk) + 8 * (pp & 1);
+    part[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  }
+  s16x8 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = part[0][j];
+    v[4 + j] = part[1][j];
+  }
+  return __builtin_bit_cast(bfrag, v);
+}
+
+// Registers 8*s .. 8*s+7 of an accumulator tile -> operand-B fragment of k-step s.
+__device__ __forceinline__ bfrag acc_frag(const f32x16& a, int s) {
+  u32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a[8 * s + 2 * j], a[8 * s + 2 * j + 1]);
+  return __builtin_bit_cast(bfrag, v);
+}
+
+// Global -> register -> LDS staging of a [64][HS] tile by 256 threads.
+template <int HS>
+struct Stage64 {
+  static constexpr int CPR = HS / 8;
+  static constexpr int NLD = 64 * CPR / 256;
+  u32x4 reg[NLD];
+  __device__ __forceinline__ void issue(const bf16_t* base, int row0, int nrows, long long ts, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + 256 * i, row = id / CPR, ch = id % CPR;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      if (row0 + row < nrows)
+        z = *reinterpret_cast<const u32x4*>(base + (long long)(row0 + row) * ts + ch * 8);
+      reg[i] = z;
+    }
+  }
+  __device__ __forceinline__ void commit(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int id = tid + 256 * i, row = id / CPR, ch = id % CPR;
+      *reinterpret_cast<u32x4*>(tile + row * (HS * 2) + 16 * swz<HS>(row, ch)) = reg[i];
+    }
+  }
+};
+
+// A wave's [32][HS] output tile, held transposed (rows = d on registers, column = lane), is
+// turned into whole rows through LDS and stored with 16-byte accesses.
+template <int HS>
+__device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)[HS / 32], float mul, bf16_t* out,
+                                             long long ts, int row0, int nrows, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < HS / 32; ++dt) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = 32 * dt + 8 * g4 + 4 * hh;
+      u32x2 w;
+      w[0] = pack_bf16x2(acc[dt][4 * g4] * mul, acc[dt][4 * g4 + 1] * mul);
+      w[1] = pack_bf16x2(acc[dt][4 * g4 + 2] * mul, acc[dt][4 * g4 + 3] * mul);
+      *reinterpret_cast<u32x2*>(wave_lds + r * (HS * 2) + d0 * 2) = w;
+    }
+  }
+  constexpr int CPR = HS / 8;
+#pragma unroll
+  for (int i = 0; i < 32 * CPR / 64; ++i) {
+    const int id = lane + 64 * i, row = id / CPR, ch = id % CPR;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wave_lds + row * (HS * 2) + ch * 16);
+    if (row0 + row < nrows) *reinterpret_cast<u32x4*>(out + (long long)(row0 + row) * ts + ch * 8) = v;
+  }
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------
+// Forward
+// ------------------------------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int BH = p.B * p.nh;
+  const int nqt = (p.Tq + 127) / 128;
+  const int qt = nqt - 1 - (int)blockIdx.x / BH;  // heaviest (latest) query tiles first
+  const int bh = (int)blockIdx.x % BH, b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
+  const int q0 = qt * 128, off = p.Tk - p.Tq;
+  const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
+  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
+  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
+
+  const int qrow = q0 + wave * 32 + r;
+  bfrag qf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = zero_frag();
+    if (qrow < p.Tq) qf[ks] = *reinterpret_cast<const bfrag*>(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8);
+  }
+
+  int kv_end = q0 + 128 + off;
+  if (kv_end > p.Tk) kv_end = p.Tk;
+  const int ntiles = (kv_end + 63) / 64;
+  const int wave_qmax = q0 + wave * 32 + 31;
+
+  Stage64<HS> ks_, vs_;
+  ks_.issue(kp, 0, p.Tk, p.k_ts, tid);
+  vs_.issue(vp, 0, p.Tk, p.v_ts, tid);
+  ks_.commit(smem, tid);
+  vs_.commit(smem + TILE, tid);
+
+  f32x16 oacc[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float c = p.scale * kLog2e;
+  int qlim = qrow + off;
+  if (qlim > p.Tk - 1) qlim = p.Tk - 1;
+
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) {
+      ks_.issue(kp, (t + 1) * 64, p.Tk, p.k_ts, tid);
+      vs_.issue(vp, (t + 1) * 64, p.Tk, p.v_ts, tid);
+    }
+    __syncthreads();
+    const char* kb = smem + (t & 1) * 2 * TILE;
+    const char* vb = kb + TILE;
+    const int kv0 = t * 64;
+    if (kv0 <= wave_qmax + off) {  // wave-uniform: some key of this tile is visible to the wave
+      f32x16 s[2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) s[sub] = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s[sub]);
+      }
+      const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > p.Tk);
+      if (need_mask) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kv0 + sub * 32 + acc_row(i, hh) > qlim) s[sub][i] = -INFINITY;
+      }
+      float mx = s[0][0];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[sub][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+      const float mc = m_new * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][i], c, -mc));
+          s[sub][i] = pv;
+          rs += pv;
+        }
+      l = l * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bfrag pb = acc_frag(s[sub], s2);
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) oacc[dt] = mfma32(tr_frag<HS>(vb, sub * 32, s2, dt, lane), pb, oacc[dt]);
+        }
+    }
+    if (t + 1 < ntiles) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      ks_.commit(nb, tid);
+      vs_.commit(nb + TILE, tid);
+    }
+  }
+
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  if (hh == 0 && qrow < p.Tq) p.lse[((long long)b * p.nh + h) * p.Tq + qrow] = m * p.scale + __logf(l);
+  __syncthreads();  // all waves are done with the K/V tiles before the region is reused
+  bf16_t* op = (bf16_t*)p.o + b * p.o_bs + h * HS;
+  store_tile_T<HS>(smem + wave * 32 * HS * 2, oacc, inv, op, p.o_ts, q0 + wave * 32, p.Tq, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// delta[b, h, q] = sum_d dO * O
+// ------------------------------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+  const long long total = (long long)p.B * p.Tq * p.nh;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int h = (int)(i % p.nh);
+  const long long bt = i / p.nh;
+  const int t = (int)(bt % p.Tq), b = (int)(bt / p.Tq);
+  const bf16_t* o = (const bf16_t*)p.o + b * p.o_bs + (long long)t * p.o_ts + h * HS;
+  const bf16_t* d = (const bf16_t*)p.dout + b * p.do_bs + (long long)t * p.do_ts + h * HS;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < HS / 8; ++c) {
+    float a[8], g[8];
+    load8(o + c * 8, a);
+    load8(d + c * 8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += a[j] * g[j];
+  }
+  p.delta[((long long)b * p.nh + h) * p.Tq + t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, dQ: one workgroup = 128 queries, sweeps the keys.
+// ------------------------------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int BH = p.B * p.nh;
+  const int nqt = (p.Tq + 127) / 128;
+  const int qt = nqt - 1 - (int)blockIdx.x / BH;
+  const int bh = (int)blockIdx.x % BH, b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
+  const int q0 = qt * 128, off = p.Tk - p.Tq;
+  const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
+  const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + h * HS;
+  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
+  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
+
+  const int qrow = q0 + wave * 32 + r;
+  bfrag qf[NK], dof[NK];
+  float lse2 = INFINITY, dlt = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = zero_frag();
+    dof[ks] = zero_frag();
+  }
+  if (qrow < p.Tq) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      qf[ks] = *reinterpret_cast<const bfrag*>(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8);
+      dof[ks] = *reinterpret_cast<const bfrag*>(dop + (long long)qrow * p.do_ts + ks * 16 + hh * 8);
+    }
+    lse2 = p.lse[((long long)b * p.nh + h) * p.Tq + qrow] * kLog2e;
+    dlt = p.delta[((long long)b * p.nh + h) * p.Tq + qrow];
+  }
+
+  int kv_end = q0 + 128 + off;
+  if (kv_end > p.Tk) kv_end = p.Tk;
+  const int ntiles = (kv_end + 63) / 64;
+  const int wave_qmax = q0 + wave * 32 + 31;
+
+  Stage64<HS> ks_, vs_;
+  ks_.issue(kp, 0, p.Tk, p.k_ts, tid);
+  vs_.issue(vp, 0, p.Tk, p.v_ts, tid);
+  ks_.commit(smem, tid);
+  vs_.commit(smem + TILE, tid);
+
+  f32x16 dqacc[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqacc[dt][i] = 0.f;
+  const float c = p.scale * kLog2e;
+  int qlim = qrow + off;
+  if (qlim > p.Tk - 1) qlim = p.Tk - 1;
+
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) {
+      ks_.issue(kp, (t + 1) * 64, p.Tk, p.k_ts, tid);
+      vs_.issue(vp, (t + 1) * 64, p.Tk, p.v_ts, tid);
+    }
+    __syncthreads();
+    const char* kb = smem + (t & 1) * 2 * TILE;
+    const char* vb = kb + TILE;
+    const int kv0 = t * 64;
+    if (kv0 <= wave_qmax + off) {
+      const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > p.Tk);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[i] = 0.f;
+          dp[i] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(vb, sub * 32 + r, ks, hh), dof[ks], dp);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -lse2));
+          if (need_mask && (kv0 + sub * 32 + acc_row(i, hh) > qlim)) pv = 0.f;
+          s[i] = pv * (dp[i] - dlt);  // dS^T
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bfrag dsb = acc_frag(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) dqacc[dt] = mfma32(tr_frag<HS>(kb, sub * 32, s2, dt, lane), dsb, dqacc[dt]);
+        }
+      }
+    }
+    if (t + 1 < ntiles) {
+      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      ks_.commit(nb, tid);
+      vs_.commit(nb + TILE, tid);
+    }
+  }
+  __syncthreads();
+  bf16_t* dqp = (bf16_t*)p.dq + b * p.dq_bs + h * HS;
+  store_tile_T<HS>(smem + wave * 32 * HS * 2, dqacc, p.scale, dqp, p.dq_ts, q0 + wave * 32, p.Tq, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, dK/dV: one workgroup = 128 keys of one (batch, kv head); each wave keeps dK^T and
+// dV^T of its 32 keys in registers and sweeps the query heads of the group x the query tiles.
+// ------------------------------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2, BUF = 2 * TILE + 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int BHk = p.B * p.nkv;
+  const int kt = (int)blockIdx.x / BHk;  // low key tiles (most queries) first
+  const int bh = (int)blockIdx.x % BHk, b = bh / p.nkv, kvh = bh % p.nkv;
+  const int G = p.nh / p.nkv;
+  const int k0 = kt * 128, off = p.Tk - p.Tq;
+  const int kw0 = k0 + wave * 32;
+  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
+  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
+
+  const int key = kw0 + r;
+  bfrag kf[NK], vf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    kf[ks] = zero_frag();
+    vf[ks] = zero_frag();
+    if (key < p.Tk) {
+      kf[ks] = *reinterpret_cast<const bfrag*>(kp + (long long)key * p.k_ts + ks * 16 + hh * 8);
+      vf[ks] = *reinterpret_cast<const bfrag*>(vp + (long long)key * p.v_ts + ks * 16 + hh * 8);
+    }
+  }
+  int q_start = k0 - off;
+  if (q_start < 0) q_start = 0;
+  q_start = (q_start / 64) * 64;
+  const int nqt = (p.Tq - q_start + 63) / 64;
+  const int niter = (nqt > 0 ? nqt : 0) * G;
+
+  f32x16 dkacc[ND], dvacc[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dkacc[dt][i] = 0.f;
+      dvacc[dt][i] = 0.f;
+    }
+  const float c = p.scale * kLog2e;
+
+  Stage64<HS> qs_, ds_;
+  float stat = 0.f;  // threads 0..63: lse*log2e of query tid; threads 64..127: delta of query tid-64
+  auto issue = [&](int it) {
+    const int hq = kvh * G + it / nqt, qt0 = q_start + (it % nqt) * 64;
+    const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + hq * HS;
+    const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + hq * HS;
+    qs_.issue(qp, qt0, p.Tq, p.q_ts, tid);
+    ds_.issue(dop, qt0, p.Tq, p.do_ts, tid);
+    if (tid < 128) {
+      const int qi = qt0 + (tid & 63);
+      const long long o = ((long long)b * p.nh + hq) * p.Tq + qi;
+      if (tid < 64) stat = (qi < p.Tq) ? p.lse[o] * kLog2e : INFINITY;
+      else stat = (qi < p.Tq) ? p.delta[o] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * BUF;
+    qs_.commit(base, tid);
+    ds_.commit(base + TILE, tid);
+    if (tid < 128) *reinterpret_cast<float*>(base + 2 * TILE + tid * 4) = stat;
+  };
+
+  if (niter > 0) {
+    issue(0);
+    commit(0);
+  }
+  for (int it = 0; it < niter; ++it) {
+    if (it + 1 < niter) issue(it + 1);
+    __syncthreads();
+    const char* qb = smem + (it & 1) * BUF;
+    const char* dob = qb + TILE;
+    const char* stb = qb + 2 * TILE;
+    const int qt0 = q_start + (it % nqt) * 64;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int qs0 = qt0 + sub * 32;
+      if (qs0 + 31 + off >= kw0 && qs0 < p.Tq) {  // wave-uniform: some (query, key) pair is visible
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[i] = 0.f;
+          dp[i] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(qb, sub * 32 + r, ks, hh), kf[ks], s);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(dob, sub * 32 + r, ks, hh), vf[ks], dp);
+        const bool need_mask = (kw0 + 31 > qs0 + off);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int rr = sub * 32 + 8 * g4 + 4 * hh;
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(stb + rr * 4);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(stb + 256 + rr * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * g4 + j;
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[j]));
+            if (need_mask && (key > qt0 + rr + j + off)) pv = 0.f;
+            s[i] = pv;                    // P
+            dp[i] = pv * (dp[i] - d4[j]);  // dS
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bfrag pb = acc_frag(s, s2);
+          const bfrag dsb = acc_frag(dp, s2);
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) {
+            dvacc[dt] = mfma32(tr_frag<HS>(dob, sub * 32, s2, dt, lane), pb, dvacc[dt]);
+            dkacc[dt] = mfma32(tr_frag<HS>(qb, sub * 32, s2, dt, lane), dsb, dkacc[dt]);
+          }
+        }
+      }
+    }
+    if (it + 1 < niter) commit((it + 1) & 1);
+  }
+  __syncthreads();
+  bf16_t* dkp = (bf16_t*)p.dk + b * p.dk_bs + kvh * HS;
+  bf16_t* dvp = (bf16_t*)p.dv + b * p.dv_bs + kvh * HS;
+  char* wl = smem + wave * 32 * HS * 2;
+  store_tile_T<HS>(wl, dkacc, p.scale, dkp, p.dk_ts, kw0, p.Tk, lane);
+  store_tile_T<HS>(wl, dvacc, 1.f, dvp, p.dv_ts, kw0, p.Tk, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------
+template <int HS>
+static void fwd_launch(const AttnParams& p, hipStream_t st) {
+  const int nqt = (p.Tq + 127) / 128;
+  const size_t lds = 4 * 64 * HS * 2;
+  hipLaunchKernelGGL((attn_fwd_kernel<HS>), dim3(nqt * p.B * p.nh), dim3(256), lds, st, p);
+}
+
+template <int HS>
+static void bwd_launch(const AttnParams& p, hipStream_t st) {
+  const long long rows = (long long)p.B * p.Tq * p.nh;
+  hipLaunchKernelGGL((attn_delta_kernel<HS>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+  const int nkt = (p.Tk + 127) / 128;
+  const size_t lds_kv = 2 * (2 * 64 * HS * 2 + 512);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_kv);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
+  const int nqt = (p.Tq + 127) / 128;
+  const size_t lds_q = 4 * 64 * HS * 2;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HS>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
+}
+
+void attn_fwd(const AttnParams& p, hipStream_t st) {
+  if (p.B == 0 || p.Tq == 0) return;
+  if (p.hs == 64) fwd_launch<64>(p, st);
+  else fwd_launch<128>(p, st);
+}
+
+void attn_bwd(const AttnParams& p, hipStream_t st) {
+  if (p.B == 0 || p.Tq == 0) return;
+  if (p.hs == 64) bwd_launch<64>(p, st);
+  else bwd_launch<128>(p, st);
+}
+
+}  // namespace dpa

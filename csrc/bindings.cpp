@@ -1,0 +1,423 @@
+// torch.ops.dpa.* : the only translation unit that sees PyTorch. It validates shapes, dtypes
+// and strides on the host (a kernel launched on operands that do not match its indexing can
+// fault the GPU), allocates outputs through the caching allocator and forwards raw pointers
+// plus the current HIP stream to the launchers in kernels.h.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <cmath>
+#include <optional>
+#include <tuple>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+using at::Tensor;
+
+hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+bool is_bf16(const Tensor& t) { return t.scalar_type() == at::kBFloat16; }
+
+void check_act(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must live on the GPU");
+  TORCH_CHECK(t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kFloat, name, " must be bf16 or fp32");
+  TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, " must be 16-byte aligned");
+}
+
+const void* opt_ptr(const std::optional<Tensor>& t) { return t.has_value() ? t->data_ptr() : nullptr; }
+
+// ---------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_fwd(const Tensor& x, const std::optional<Tensor>& res,
+                                                         const Tensor& w, const Tensor& b, double eps) {
+  check_act(x, "x");
+  check_act(w, "weight");
+  check_act(b, "bias");
+  const int64_t C = x.size(-1);
+  TORCH_CHECK(C % 8 == 0 && C <= dpa::layernorm_max_cols(), "layernorm: unsupported width ", C);
+  TORCH_CHECK(w.numel() == C && b.numel() == C, "layernorm: weight/bias size mismatch");
+  TORCH_CHECK(w.scalar_type() == x.scalar_type() && b.scalar_type() == x.scalar_type(),
+              "layernorm: x, weight and bias must share a dtype");
+  const int64_t rows = x.numel() / C;
+  Tensor y = at::empty_like(x);
+  Tensor sum;
+  if (res.has_value()) {
+    check_act(*res, "residual");
+    TORCH_CHECK(res->sizes() == x.sizes() && res->scalar_type() == x.scalar_type(), "layernorm: residual mismatch");
+    sum = at::empty_like(x);
+  }
+  Tensor mean = at::empty({rows}, x.options().dtype(at::kFloat));
+  Tensor rstd = at::empty({rows}, x.options().dtype(at::kFloat));
+  if (rows > 0)
+    dpa::layernorm_fwd(x.data_ptr(), opt_ptr(res), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                       res.has_value() ? sum.data_ptr() : nullptr, mean.data_ptr<float>(), rstd.data_ptr<float>(),
+                       (int)rows, (int)C, (float)eps, is_bf16(x), cur_stream());
+  return {y, sum, mean, rstd};
+}
+
+std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& w,
+                                                 const Tensor& mean, const Tensor& rstd,
+                                                 const std::optional<Tensor>& dres) {
+  check_act(dy, "dy");
+  check_act(x, "x");
+  check_act(w, "weight");
+  const int64_t C = x.size(-1);
+  TORCH_CHECK(C % 8 == 0 && C <= 4096, "layernorm backward: unsupported width ", C);
+  TORCH_CHECK(dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type(), "layernorm backward: dy mismatch");
+  TORCH_CHECK(w.numel() == C && w.scalar_type() == x.scalar_type(), "layernorm backward: weight mismatch");
+  const int64_t rows = x.numel() / C;
+  TORCH_CHECK(mean.numel() == rows && rstd.numel() == rows && mean.scalar_type() == at::kFloat &&
+                  rstd.scalar_type() == at::kFloat,
+              "layernorm backward: statistics mismatch");
+  if (dres.has_value()) {
+    check_act(*dres, "dres");
+    TORCH_CHECK(dres->sizes() == x.sizes() && dres->scalar_type() == x.scalar_type(), "dres mismatch");
+  }
+  Tensor dx = at::empty_like(x);
+  Tensor dw = at::empty_like(w);
+  Tensor db = at::empty_like(w);
+  if (rows == 0) {
+    dw.zero_();
+    db.zero_();
+    return {dx, dw, db};
+  }
+  const int nparts = dpa::layernorm_bwd_parts((int)rows);
+  Tensor scratch = at::empty({2 * (int64_t)nparts * C}, x.options().dtype(at::kFloat));
+  dpa::layernorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
+                     opt_ptr(dres), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), scratch.data_ptr<float>(), nparts,
+                     (int)rows, (int)C, false, is_bf16(x), cur_stream());
+  return {dx, dw, db};
+}
+
+// ---------------------------------------------------------------------------------------
+void adamw_step(Tensor master, Tensor m, Tensor v, const Tensor& grad, const std::optional<Tensor>& param_out,
+                std::vector<int64_t> seg_ends, std::vector<double> seg_wds, double lr, double beta1, double beta2,
+                double eps, int64_t step, const std::optional<Tensor>& norm2, double max_norm, double grad_mul) {
+  const int64_t n = master.numel();
+  TORCH_CHECK(n % 8 == 0, "adamw: flat buffers must be padded to a multiple of 8 elements");
+  for (const Tensor* t : {&master, &m, &v}) {
+    check_act(*t, "adamw state");
+    TORCH_CHECK(t->scalar_type() == at::kFloat && t->numel() == n, "adamw: state must be fp32 of equal size");
+  }
+  check_act(grad, "grad");
+  TORCH_CHECK(grad.numel() == n, "adamw: grad size mismatch");
+  if (param_out.has_value()) {
+    check_act(*param_out, "param_out");
+    TORCH_CHECK(param_out->numel() == n, "adamw: param_out size mismatch");
+  }
+  TORCH_CHECK(seg_ends.size() == seg_wds.size() && !seg_ends.empty() && seg_ends.size() <= 64,
+              "adamw: 1..64 weight-decay segments");
+  dpa::AdamSegs segs;
+  segs.nseg = (int)seg_ends.size();
+  int64_t prev = 0;
+  for (size_t i = 0; i < seg_ends.size(); ++i) {
+    TORCH_CHECK(seg_ends[i] % 8 == 0 && seg_ends[i] >= prev, "adamw: segment ends must ascend in multiples of 8");
+    prev = seg_ends[i];
+    segs.end[i] = seg_ends[i];
+    segs.wd[i] = (float)seg_wds[i];
+  }
+  TORCH_CHECK(prev == n, "adamw: segments must cover the buffer");
+  const float* n2 = nullptr;
+  if (norm2.has_value()) {
+    TORCH_CHECK(norm2->is_cuda() && norm2->scalar_type() == at::kFloat && norm2->numel() == 1, "norm2: 1 fp32");
+    n2 = norm2->data_ptr<float>();
+  }
+  if (n == 0) return;
+  const float bc1 = 1.f - (float)std::pow(beta1, (double)step);
+  const float bc2s = (float)std::sqrt(1.0 - std::pow(beta2, (double)step));
+  dpa::adamw_step(master.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(), grad.data_ptr(), is_bf16(grad),
+                  param_out.has_value() ? param_out->data_ptr() : nullptr,
+                  param_out.has_value() ? is_bf16(*param_out) : false, n, segs, (float)lr, (float)beta1,
+                  (float)beta2, (float)eps, bc1, bc2s, n2, (float)max_norm, (float)grad_mul, cur_stream());
+}
+
+void sumsq(const Tensor& g, Tensor out, bool accumulate) {
+  check_act(g, "g");
+  TORCH_CHECK(g.numel() % 8 == 0, "sumsq: length must be a multiple of 8");
+  TORCH_CHECK(out.is_cuda() && out.scalar_type() == at::kFloat && out.numel() == 1, "sumsq: out is 1 fp32");
+  if (g.numel() == 0) {
+    if (!accumulate) out.zero_();
+    return;
+  }
+  Tensor partials = at::empty({dpa::sumsq_parts(g.numel())}, out.options());
+  dpa::sumsq(g.data_ptr(), is_bf16(g), g.numel(), partials.data_ptr<float>(), out.data_ptr<float>(), accumulate,
+             cur_stream());
+}
+
+// ---------------------------------------------------------------------------------------
+void check_logits(const Tensor& logits, const Tensor& targets) {
+  TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && logits.stride(1) == 1, "logits: [rows, V], unit inner stride");
+  TORCH_CHECK(logits.scalar_type() == at::kBFloat16 || logits.scalar_type() == at::kFloat, "logits: bf16 or fp32");
+  TORCH_CHECK(logits.size(1) % 8 == 0 && logits.stride(0) % 8 == 0, "logits: V and row stride multiples of 8");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(logits.data_ptr()) % 16 == 0, "logits: 16-byte aligned");
+  TORCH_CHECK(targets.is_cuda() && targets.scalar_type() == at::kLong && targets.is_contiguous() &&
+                  targets.numel() == logits.size(0),
+              "targets: int64 [rows]");
+}
+
+Tensor xent_fused(Tensor logits, const Tensor& targets, const Tensor& grad_scale, int64_t ignore_index,
+                  bool write_grad) {
+  check_logits(logits, targets);
+  TORCH_CHECK(grad_scale.is_cuda() && grad_scale.scalar_type() == at::kFloat && grad_scale.numel() == 1);
+  Tensor loss = at::empty({logits.size(0)}, logits.options().dtype(at::kFloat));
+  dpa::xent(0, logits.data_ptr(), is_bf16(logits), (const long long*)targets.data_ptr<int64_t>(),
+            loss.data_ptr<float>(), nullptr, nullptr, nullptr, nullptr, grad_scale.data_ptr<float>(),
+            (int)logits.size(0), (int)logits.size(1), (int)logits.stride(0), 0, ignore_index, write_grad,
+            cur_stream());
+  return loss;
+}
+
+std::tuple<Tensor, Tensor, Tensor> xent_stats(const Tensor& logits, const Tensor& targets, int64_t vocab_start,
+                                              int64_t ignore_index) {
+  check_logits(logits, targets);
+  auto opt = logits.options().dtype(at::kFloat);
+  Tensor mx = at::empty({logits.size(0)}, opt), sm = at::empty({logits.size(0)}, opt),
+         tg = at::empty({logits.size(0)}, opt);
+  dpa::xent(1, logits.data_ptr(), is_bf16(logits), (const long long*)targets.data_ptr<int64_t>(), nullptr,
+            mx.data_ptr<float>(), sm.data_ptr<float>(), tg.data_ptr<float>(), nullptr, nullptr, (int)logits.size(0),
+            (int)logits.size(1), (int)logits.stride(0), (int)vocab_start, ignore_index, false, cur_stream());
+  return {mx, sm, tg};
+}
+
+Tensor xent_grad(Tensor logits, const Tensor& targets, const Tensor& lse, const Tensor& tgt_logit,
+                 const Tensor& grad_scale, int64_t vocab_start, int64_t ignore_index, bool write_grad) {
+  check_logits(logits, targets);
+  for (const Tensor* t : {&lse, &tgt_logit})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->is_contiguous() && t->numel() == logits.size(0));
+  TORCH_CHECK(grad_scale.is_cuda() && grad_scale.scalar_type() == at::kFloat && grad_scale.numel() == 1);
+  Tensor loss = at::empty({logits.size(0)}, logits.options().dtype(at::kFloat));
+  dpa::xent(2, logits.data_ptr(), is_bf16(logits), (const long long*)targets.data_ptr<int64_t>(),
+            loss.data_ptr<float>(), nullptr, nullptr, const_cast<float*>(tgt_logit.data_ptr<float>()),
+            lse.data_ptr<float>(), grad_scale.data_ptr<float>(), (int)logits.size(0), (int)logits.size(1),
+            (int)logits.stride(0), (int)vocab_start, ignore_index, write_grad, cur_stream());
+  return loss;
+}
+
+// ---------------------------------------------------------------------------------------
+Tensor embed_fwd(const Tensor& idx, const Tensor& wte, const std::optional<Tensor>& pos, int64_t pos0) {
+  check_act(wte, "wte");
+  TORCH_CHECK(idx.is_cuda() && idx.scalar_type() == at::kLong && idx.is_contiguous() && idx.dim() == 2,
+              "idx: int64 [B, T]");
+  const int64_t C = wte.size(1), T = idx.size(1);
+  TORCH_CHECK(C % 8 == 0, "embedding width must be a multiple of 8");
+  if (pos.has_value()) {
+    check_act(*pos, "pos");
+    TORCH_CHECK(pos->size(1) == C && pos->scalar_type() == wte.scalar_type() && pos0 + T <= pos->size(0),
+                "position table too short or mismatched");
+  }
+  Tensor out = at::empty({idx.size(0), T, C}, wte.options());
+  dpa::embed_fwd((const long long*)idx.data_ptr<int64_t>(), wte.data_ptr(), opt_ptr(pos), out.data_ptr(),
+                 idx.numel(), (int)T, (int)pos0, (int)C, is_bf16(wte), cur_stream());
+  return out;
+}
+
+void embed_bwd(const Tensor& dout, const Tensor& ids_sorted, const Tensor& perm, Tensor dwte) {
+  check_act(dout, "dout");
+  check_act(dwte, "dwte");
+  const int64_t C = dwte.size(1), N = ids_sorted.numel();
+  TORCH_CHECK(dout.numel() == N * C && dout.scalar_type() == dwte.scalar_type(), "embed_bwd: dout mismatch");
+  for (const Tensor* t : {&ids_sorted, &perm})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kLong && t->is_contiguous() && t->numel() == N);
+  dpa::embed_bwd(dout.data_ptr(), (const long long*)ids_sorted.data_ptr<int64_t>(),
+                 (const long long*)perm.data_ptr<int64_t>(), dwte.data_ptr(), N, (int)C, is_bf16(dwte), cur_stream());
+}
+
+void pos_bwd(const Tensor& dout, Tensor dpos, int64_t pos0) {
+  check_act(dout, "dout");
+  check_act(dpos, "dpos");
+  TORCH_CHECK(dout.dim() == 3 && dout.size(2) == dpos.size(1) && dout.scalar_type() == dpos.scalar_type() &&
+                  pos0 + dout.size(1) <= dpos.size(0),
+              "pos_bwd: shape mismatch");
+  dpa::pos_bwd(dout.data_ptr(), dpos.data_ptr(), (int)dout.size(0), (int)dout.size(1), (int)pos0, (int)dout.size(2),
+               is_bf16(dpos), cur_stream());
+}
+
+// ---------------------------------------------------------------------------------------
+Tensor gelu_fwd(const Tensor& x) {
+  check_act(x, "x");
+  TORCH_CHECK(x.numel() % 8 == 0);
+  Tensor y = at::empty_like(x);
+  dpa::gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), is_bf16(x), cur_stream());
+  return y;
+}
+Tensor gelu_bwd(const Tensor& dy, const Tensor& x) {
+  check_act(x, "x");
+  check_act(dy, "dy");
+  TORCH_CHECK(x.numel() % 8 == 0 && dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type());
+  Tensor dx = at::empty_like(x);
+  dpa::gelu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), is_bf16(x), cur_stream());
+  return dx;
+}
+Tensor swiglu_fwd(const Tensor& h) {
+  check_act(h, "h");
+  const int64_t U = h.size(-1) / 2;
+  TORCH_CHECK(h.size(-1) % 16 == 0, "swiglu: inner width must be a multiple of 16");
+  auto sizes = h.sizes().vec();
+  sizes.back() = U;
+  Tensor y = at::empty(sizes, h.options());
+  dpa::swiglu_fwd(h.data_ptr(), y.data_ptr(), h.numel() / (2 * U), (int)U, is_bf16(h), cur_stream());
+  return y;
+}
+Tensor swiglu_bwd(const Tensor& dy, const Tensor& h) {
+  check_act(h, "h");
+  check_act(dy, "dy");
+  const int64_t U = h.size(-1) / 2;
+  TORCH_CHECK(h.size(-1) % 16 == 0 && dy.numel() * 2 == h.numel() && dy.scalar_type() == h.scalar_type());
+  Tensor dh = at::empty_like(h);
+  dpa::swiglu_bwd(dy.data_ptr(), h.data_ptr(), dh.data_ptr(), h.numel() / (2 * U), (int)U, is_bf16(h), cur_stream());
+  return dh;
+}
+
+// ---------------------------------------------------------------------------------------
+// A [B, T, H, hs] view with unit inner stride and head stride hs (a slice of a fused projection).
+void check_heads(const Tensor& t, const char* name, int64_t hs) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kBFloat16 && t.dim() == 4, name, ": bf16 [B, T, H, hs]");
+  TORCH_CHECK(t.size(3) == hs && t.stride(3) == 1 && (t.size(2) == 1 || t.stride(2) == hs), name,
+              ": heads must be packed");
+  TORCH_CHECK(t.stride(1) % 8 == 0 && t.stride(0) % 8 == 0 && reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0,
+              name, ": 16-byte aligned rows");
+}
+
+dpa::AttnParams attn_params(const Tensor& q, const Tensor& k, const Tensor& v, double scale) {
+  const int64_t hs = q.size(3);
+  TORCH_CHECK(hs == 64 || hs == 128, "attention: head size must be 64 or 128, got ", hs);
+  check_heads(q, "q", hs);
+  check_heads(k, "k", hs);
+  check_heads(v, "v", hs);
+  TORCH_CHECK(k.size(0) == q.size(0) && v.sizes() == k.sizes(), "attention: k/v shape mismatch");
+  TORCH_CHECK(q.size(2) % k.size(2) == 0, "attention: n_head must be a multiple of n_kv_heads");
+  TORCH_CHECK(k.size(1) >= q.size(1), "attention: Tk < Tq");
+  dpa::AttnParams p{};
+  p.q = q.data_ptr();
+  p.k = k.data_ptr();
+  p.v = v.data_ptr();
+  p.B = (int)q.size(0);
+  p.Tq = (int)q.size(1);
+  p.nh = (int)q.size(2);
+  p.Tk = (int)k.size(1);
+  p.nkv = (int)k.size(2);
+  p.hs = (int)hs;
+  p.q_bs = q.stride(0);
+  p.q_ts = (int)q.stride(1);
+  p.k_bs = k.stride(0);
+  p.k_ts = (int)k.stride(1);
+  p.v_bs = v.stride(0);
+  p.v_ts = (int)v.stride(1);
+  p.scale = (float)scale;
+  return p;
+}
+
+std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale) {
+  dpa::AttnParams p = attn_params(q, k, v, scale);
+  Tensor o = at::empty({q.size(0), q.size(1), q.size(2), q.size(3)}, q.options());
+  Tensor lse = at::empty({q.size(0), q.size(2), q.size(1)}, q.options().dtype(at::kFloat));
+  p.o = o.data_ptr();
+  p.o_bs = o.stride(0);
+  p.o_ts = (int)o.stride(1);
+  p.lse = lse.data_ptr<float>();
+  dpa::attn_fwd(p, cur_stream());
+  return {o, lse};
+}
+
+void attn_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
+              const Tensor& lse, Tensor dq, Tensor dk, Tensor dv, double scale) {
+  dpa::AttnParams p = attn_params(q, k, v, scale);
+  const int64_t hs = q.size(3);
+  check_heads(dout, "dout", hs);
+  check_heads(o, "o", hs);
+  check_heads(dq, "dq", hs);
+  check_heads(dk, "dk", hs);
+  check_heads(dv, "dv", hs);
+  TORCH_CHECK(dout.sizes() == q.sizes() && o.sizes() == q.sizes() && dq.sizes() == q.sizes() &&
+                  dk.sizes() == k.sizes() && dv.sizes() == v.sizes(),
+              "attention backward: shape mismatch");
+  TORCH_CHECK(lse.is_cuda() && lse.scalar_type() == at::kFloat && lse.is_contiguous() &&
+                  lse.numel() == q.size(0) * q.size(1) * q.size(2),
+              "attention backward: lse mismatch");
+  Tensor delta = at::empty_like(lse);
+  p.o = o.data_ptr();
+  p.o_bs = o.stride(0);
+  p.o_ts = (int)o.stride(1);
+  p.lse = lse.data_ptr<float>();
+  p.dout = dout.data_ptr();
+  p.do_bs = dout.stride(0);
+  p.do_ts = (int)dout.stride(1);
+  p.delta = delta.data_ptr<float>();
+  p.dq = dq.data_ptr();
+  p.dq_bs = dq.stride(0);
+  p.dq_ts = (int)dq.stride(1);
+  p.dk = dk.data_ptr();
+  p.dk_bs = dk.stride(0);
+  p.dk_ts = (int)dk.stride(1);
+  p.dv = dv.data_ptr();
+  p.dv_bs = dv.stride(0);
+  p.dv_ts = (int)dv.stride(1);
+  dpa::attn_bwd(p, cur_stream());
+}
+
+void rope_(Tensor x, const Tensor& cos_t, const Tensor& sin_t, int64_t pos0, bool inverse) {
+  TORCH_CHECK(x.is_cuda() && x.dim() == 4 && (x.scalar_type() == at::kBFloat16 || x.scalar_type() == at::kFloat),
+              "rope: [B, T, H, hs] bf16/fp32");
+  const int64_t hs = x.size(3);
+  TORCH_CHECK(hs % 8 == 0 && x.stride(3) == 1 && (x.size(2) == 1 || x.stride(2) == hs), "rope: packed heads, hs % 8 == 0");
+  const int64_t esz = x.element_size();
+  TORCH_CHECK((x.stride(1) * esz) % 16 == 0 && (x.stride(0) * esz) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
+              "rope: 16-byte aligned rows");
+  for (const Tensor* t : {&cos_t, &sin_t})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->is_contiguous() && t->dim() == 2 &&
+                    t->size(1) == hs / 2 && pos0 + x.size(1) <= t->size(0),
+                "rope: cos/sin tables are fp32 [>=pos0+T, hs/2]");
+  dpa::rope_inplace(x.data_ptr(), x.stride(0), (int)x.stride(1), (int)x.size(0), (int)x.size(1), (int)x.size(2),
+                    (int)hs, cos_t.data_ptr<float>(), sin_t.data_ptr<float>(), (int)pos0, inverse, is_bf16(x),
+                    cur_stream());
+}
+
+}  // namespace
+
+TORCH_LIBRARY(dpa, m) {
+  m.def("layernorm_fwd(Tensor x, Tensor? res, Tensor w, Tensor b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres) -> (Tensor, Tensor, Tensor)");
+  m.def("adamw_step(Tensor(a!) master, Tensor(b!) m, Tensor(c!) v, Tensor grad, Tensor? param_out, int[] seg_ends, "
+        "float[] seg_wds, float lr, float beta1, float beta2, float eps, int step, Tensor? norm2, float max_norm, "
+        "float grad_mul) -> ()");
+  m.def("sumsq(Tensor g, Tensor(a!) out, bool accumulate) -> ()");
+  m.def("xent_fused(Tensor(a!) logits, Tensor targets, Tensor grad_scale, int ignore_index, bool write_grad) -> Tensor");
+  m.def("xent_stats(Tensor logits, Tensor targets, int vocab_start, int ignore_index) -> (Tensor, Tensor, Tensor)");
+  m.def("xent_grad(Tensor(a!) logits, Tensor targets, Tensor lse, Tensor tgt_logit, Tensor grad_scale, "
+        "int vocab_start, int ignore_index, bool write_grad) -> Tensor");
+  m.def("embed_fwd(Tensor idx, Tensor wte, Tensor? pos, int pos0) -> Tensor");
+  m.def("embed_bwd(Tensor dout, Tensor ids_sorted, Tensor perm, Tensor(a!) dwte) -> ()");
+  m.def("pos_bwd(Tensor dout, Tensor(a!) dpos, int pos0) -> ()");
+  m.def("gelu_fwd(Tensor x) -> Tensor");
+  m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
+  m.def("swiglu_fwd(Tensor h) -> Tensor");
+  m.def("swiglu_bwd(Tensor dy, Tensor h) -> Tensor");
+  m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale) -> (Tensor, Tensor)");
+  m.def("attn_bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor(a!) dq, Tensor(b!) dk, "
+        "Tensor(c!) dv, float scale) -> ()");
+  m.def("rope_(Tensor(a!) x, Tensor cos_t, Tensor sin_t, int pos0, bool inverse) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("layernorm_fwd", layernorm_fwd);
+  m.impl("layernorm_bwd", layernorm_bwd);
+  m.impl("adamw_step", adamw_step);
+  m.impl("sumsq", sumsq);
+  m.impl("xent_fused", xent_fused);
+  m.impl("xent_stats", xent_stats);
+  m.impl("xent_grad", xent_grad);
+  m.impl("embed_fwd", embed_fwd);
+  m.impl("embed_bwd", embed_bwd);
+  m.impl("pos_bwd", pos_bwd);
+  m.impl("gelu_fwd", gelu_fwd);
+  m.impl("gelu_bwd", gelu_bwd);
+  m.impl("swiglu_fwd", swiglu_fwd);
+  m.impl("swiglu_bwd", swiglu_bwd);
+  m.impl("attn_fwd", attn_fwd);
+  m.impl("attn_bwd", attn_bwd);
+  m.impl("rope_", rope_);
+}

@@ -1,0 +1,74 @@
+// Host-callable launchers of the gfx950 kernels. Torch-free on purpose: the kernel sources
+// compile in seconds and the single bindings translation unit is the only one that sees
+// PyTorch headers. All launchers are asynchronous on `st` and perform no allocation.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dpa {
+
+// ---- LayerNorm -------------------------------------------------------------------------
+int layernorm_max_cols();
+int layernorm_bwd_parts(int rows);
+void layernorm_fwd(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out,
+                   float* mean, float* rstd, int rows, int C, float eps, bool is_bf16, hipStream_t st);
+void layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                   const void* dres, void* dx, void* dw, void* db, float* scratch, int nparts, int rows, int C,
+                   bool accumulate, bool is_bf16, hipStream_t st);
+
+// ---- Optimizer -------------------------------------------------------------------------
+struct AdamSegs {
+  int nseg;
+  long long end[64];  // exclusive end offset (elements, multiple of 8) of each weight-decay segment
+  float wd[64];
+};
+void adamw_step(float* master, float* m, float* v, const void* grad, bool grad_bf16, void* param_out,
+                bool param_bf16, long long n, const AdamSegs& segs, float lr, float beta1, float beta2, float eps,
+                float bc1, float bc2_sqrt, const float* norm2, float max_norm, float grad_mul, hipStream_t st);
+int sumsq_parts(long long n);
+void sumsq(const void* g, bool is_bf16, long long n, float* partials, float* out, bool accumulate, hipStream_t st);
+
+// ---- Cross-entropy ---------------------------------------------------------------------
+void xent(int mode, void* logits, bool is_bf16, const long long* targets, float* loss_rows, float* row_max,
+          float* row_sum, float* row_tgt, const float* lse_in, const float* grad_scale, int rows, int V, int ld,
+          int vocab_start, long long ignore_index, bool write_grad, hipStream_t st);
+
+// ---- Embedding -------------------------------------------------------------------------
+void embed_fwd(const long long* idx, const void* wte, const void* pos, void* out, long long N, int T_len, int pos0,
+               int C, bool is_bf16, hipStream_t st);
+void embed_bwd(const void* dout, const long long* ids_sorted, const long long* perm, void* dwte, long long N, int C,
+               bool is_bf16, hipStream_t st);
+void pos_bwd(const void* dout, void* dpos, int B, int T_len, int pos0, int C, bool is_bf16, hipStream_t st);
+
+// ---- Activations -----------------------------------------------------------------------
+void gelu_fwd(const void* x, void* y, long long n, bool is_bf16, hipStream_t st);
+void gelu_bwd(const void* dy, const void* x, void* dx, long long n, bool is_bf16, hipStream_t st);
+void swiglu_fwd(const void* h, void* y, long long M, int U, bool is_bf16, hipStream_t st);
+void swiglu_bwd(const void* dy, const void* h, void* dh, long long M, int U, bool is_bf16, hipStream_t st);
+
+// ---- Attention (bf16, head size 64 or 128, causal, GQA-native) ---------------------------
+// Element (b, t, h, d) of a tensor X lives at X + b*X_bs + t*X_ts + h*HS + d, which lets the
+// kernels read q/k/v straight out of a fused QKV projection and write dq/dk/dv straight into
+// the fused gradient buffer.
+struct AttnParams {
+  const void *q, *k, *v;
+  void* o;
+  float* lse;          // [B, nh, Tq] natural-log log-sum-exp of the scaled scores
+  const void* dout;    // backward only
+  float* delta;        // [B, nh, Tq] rowsum(dO * O)
+  void *dq, *dk, *dv;
+  int B, nh, nkv, Tq, Tk, hs;
+  long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
+  int q_ts, k_ts, v_ts, o_ts, do_ts, dq_ts, dk_ts, dv_ts;
+  float scale;
+};
+void attn_fwd(const AttnParams& p, hipStream_t st);
+void attn_bwd(const AttnParams& p, hipStream_t st);
+
+// ---- RoPE -------------------------------------------------------------------------------
+// In-place interleaved-pair rotation of `nheads` heads of size hs at x + t*ts (+ b*bs), using
+// fp32 cos/sin tables [T_total, hs/2] starting at row pos0. `inverse` applies the transpose
+// rotation (the backward of the forward rotation).
+void rope_inplace(void* x, long long bs, int ts, int B, int T_len, int nheads, int hs, const float* cos_t,
+                  const float* sin_t, int pos0, bool inverse, bool is_bf16, hipStream_t st);
+
+}  // namespace dpa

@@ -1,0 +1,267 @@
+// LayerNorm forward / backward for gfx950.
+//
+// One wave64 owns one row; the row lives in registers between the statistics pass and the
+// normalisation pass, so x is read from HBM exactly once. All global accesses are 16-byte
+// vectors. Optional fusions: residual add in the forward (y = LN(x + r), sum written back as
+// the new residual stream) and residual-gradient add in the backward (dx += dres).
+//
+// Replaces the implicit `nn.LayerNorm` kernels of the reference model
+// (reference: single-gpu/model.py:514-515,557).
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                     const T* __restrict__ w, const T* __restrict__ b,
+                                                     T* __restrict__ y, T* __restrict__ sum_out,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = C >> 3;
+  const T* xr = x + (size_t)row * C;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      load8(xr + c * 8, v[i]);
+      if (res != nullptr) {
+        float r[8];
+        load8(res + (size_t)row * C + c * 8, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] += r[j];
+        if (sum_out != nullptr) {
+          // Round through the storage dtype so the statistics see what later kernels will read.
+          store8(sum_out + (size_t)row * C + c * 8, v[i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float wv[8], bv[8], o[8];
+      load8(w + c * 8, wv);
+      load8(b + c * 8, bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+      store8(y + (size_t)row * C + c * 8, o);
+    }
+  }
+}
+
+// Backward. Each wave walks rows with a grid stride and keeps its dgamma/dbeta partial sums in
+// registers; the four waves of a block are combined through LDS and written as one partial
+// row per block. A second kernel folds the partial rows.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ part_dw,
+                                                     float* __restrict__ part_db, int rows, int C) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nchunk = C >> 3;
+  float aw[NCH][8], ab[NCH][8], wv[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      aw[i][j] = 0.f;
+      ab[i][j] = 0.f;
+      wv[i][j] = 0.f;
+    }
+    if (c < nchunk) load8(w + c * 8, wv[i]);
+  }
+  for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[NCH][8], xh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float d[8], xv[8];
+        load8(dy + (size_t)row * C + c * 8, d);
+        load8(x + (size_t)row * C + c * 8, xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          g[i][j] = d[j] * wv[i][j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+          aw[i][j] += d[j] * xh[i][j];
+          ab[i][j] += d[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+        if (dres != nullptr) {
+          float r[8];
+          load8(dres + (size_t)row * C + c * 8, r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += r[j];
+        }
+        store8(dx + (size_t)row * C + c * 8, o);
+      }
+    }
+  }
+  // Combine the 4 waves: lds[wave][C] for dw, then the same for db.
+  float* lw = lds;            // 4*C
+  float* lb = lds + 4 * C;    // 4*C
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lw[wid * C + c * 8 + j] = aw[i][j];
+        lb[wid * C + c * 8 + j] = ab[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    part_dw[(size_t)blockIdx.x * C + c] = lw[c] + lw[C + c] + lw[2 * C + c] + lw[3 * C + c];
+    part_db[(size_t)blockIdx.x * C + c] = lb[c] + lb[C + c] + lb[2 * C + c] + lb[3 * C + c];
+  }
+}
+
+// Fold `nparts` partial rows into the parameter gradients. With `accumulate` the result is
+// added to what dw/db already hold (gradient accumulation into a flat gradient buffer).
+template <typename T>
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part_dw, const float* __restrict__ part_db,
+                                     T* __restrict__ dw, T* __restrict__ db, int nparts, int C, int accumulate) {
+  __shared__ float red[2][4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int seg = threadIdx.x >> 6;  // 4 segments of the partial rows
+  float sw = 0.f, sb = 0.f;
+  if (col < C) {
+    for (int p = seg; p < nparts; p += 4) {
+      sw += part_dw[(size_t)p * C + col];
+      sb += part_db[(size_t)p * C + col];
+    }
+  }
+  red[0][seg][threadIdx.x & 63] = sw;
+  red[1][seg][threadIdx.x & 63] = sb;
+  __syncthreads();
+  if (seg == 0 && col < C) {
+    const int l = threadIdx.x;
+    float tw = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+    float tb = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    if (accumulate) {
+      tw += Cvt<T>::ld(dw + col);
+      tb += Cvt<T>::ld(db + col);
+    }
+    Cvt<T>::st(dw + col, tw);
+    Cvt<T>::st(db + col, tb);
+  }
+}
+
+static int pick_nch(int C) {
+  const int need = (C / 8 + 63) / 64;
+  int n = 1;
+  while (n < need) n <<= 1;
+  return n;
+}
+
+template <typename T>
+static void ln_fwd_launch(const T* x, const T* res, const T* w, const T* b, T* y, T* sum_out, float* mean,
+                          float* rstd, int rows, int C, float eps, hipStream_t st) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (pick_nch(C)) {
+#define DPA_CASE(N)                                                                                   \
+  case N:                                                                                             \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, x, res, w, b, y, sum_out, mean, rstd, \
+                       rows, C, eps);                                                                 \
+    break;
+    DPA_CASE(1) DPA_CASE(2) DPA_CASE(4) DPA_CASE(8) DPA_CASE(16)
+#undef DPA_CASE
+  }
+}
+
+template <typename T>
+static void ln_bwd_launch(const T* dy, const T* x, const T* w, const float* mean, const float* rstd,
+                          const T* dres, T* dx, T* dw, T* db, float* scratch, int nparts, int rows, int C,
+                          int accumulate, hipStream_t st) {
+  const dim3 grid(nparts), block(256);
+  const size_t lds = (size_t)8 * C * sizeof(float);
+  float* pw = scratch;
+  float* pb = scratch + (size_t)nparts * C;
+  switch (pick_nch(C)) {
+#define DPA_CASE(N)                                                                                     \
+  case N:                                                                                               \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, lds, st, dy, x, w, mean, rstd, dres, dx, pw, pb, \
+                       rows, C);                                                                        \
+    break;
+    DPA_CASE(1) DPA_CASE(2) DPA_CASE(4) DPA_CASE(8) DPA_CASE(16)
+#undef DPA_CASE
+  }
+  hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3((C + 63) / 64), dim3(256), 0, st, pw, pb, dw, db, nparts,
+                     C, accumulate);
+}
+
+int layernorm_max_cols() { return 16 * 64 * 8; }  // 8192; LDS in the backward: 8*C*4 B <= 160 KiB -> C <= 5120
+
+int layernorm_bwd_parts(int rows) {
+  int n = (rows + 3) / 4;
+  return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+}
+
+void layernorm_fwd(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out,
+                   float* mean, float* rstd, int rows, int C, float eps, bool is_bf16, hipStream_t st) {
+  if (is_bf16)
+    ln_fwd_launch<bf16_t>((const bf16_t*)x, (const bf16_t*)res, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y,
+                          (bf16_t*)sum_out, mean, rstd, rows, C, eps, st);
+  else
+    ln_fwd_launch<float>((const float*)x, (const float*)res, (const float*)w, (const float*)b, (float*)y,
+                         (float*)sum_out, mean, rstd, rows, C, eps, st);
+}
+
+void layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                   const void* dres, void* dx, void* dw, void* db, float* scratch, int nparts, int rows, int C,
+                   bool accumulate, bool is_bf16, hipStream_t st) {
+  if (is_bf16)
+    ln_bwd_launch<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (const bf16_t*)dres,
+                          (bf16_t*)dx, (bf16_t*)dw, (bf16_t*)db, scratch, nparts, rows, C, accumulate ? 1 : 0, st);
+  else
+    ln_bwd_launch<float>((const float*)dy, (const float*)x, (const float*)w, mean, rstd, (const float*)dres,
+                         (float*)dx, (float*)dw, (float*)db, scratch, nparts, rows, C, accumulate ? 1 : 0, st);
+}
+
+}  // namespace dpa

@@ -1,0 +1,174 @@
+// Softmax cross-entropy over a [rows, V] logits block for gfx950, with the gradient written
+// in place of the logits (the lm_head backward GEMMs consume it directly, so the fp32
+// probability matrix never exists).
+//
+// One 1024-thread workgroup owns one row; a row of up to 65536 logits is held in registers
+// between the statistics pass and the gradient pass, so the logits are read from memory once.
+//
+// Three modes share the code:
+//   FUSED  : statistics + loss + in-place gradient (single-GPU / replicated vocab)
+//   STATS  : per-row (max, sum exp(x - max), target logit) for a vocab shard
+//   GRAD   : loss/gradient from a given global log-sum-exp (after the cross-rank combine)
+// STATS + GRAD are the two halves of vocab-parallel cross-entropy: between them the caller
+// all-reduces max / sum-exp / target-logit across the vocab shards.
+//
+// Replaces `F.cross_entropy(..., ignore_index=-1)` (reference: single-gpu/model.py:689).
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+enum { XENT_FUSED = 0, XENT_STATS = 1, XENT_GRAD = 2 };
+
+constexpr int kXentThreads = 1024;
+constexpr int kXentMaxVec = 8;  // vectors of 8 logits cached per thread -> V <= 65536 in registers
+
+template <typename T, int MODE, bool CACHED>
+__global__ __launch_bounds__(kXentThreads) void xent_kernel(T* __restrict__ logits, const long long* __restrict__ targets,
+                                                            float* __restrict__ loss_rows, float* __restrict__ row_max,
+                                                            float* __restrict__ row_sum, float* __restrict__ row_tgt,
+                                                            const float* __restrict__ lse_in,
+                                                            const float* __restrict__ grad_scale, int V, int ld,
+                                                            int vocab_start, long long ignore_index, int write_grad) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  T* lr = logits + (size_t)row * ld;
+  const long long tgt = targets[row];
+  const bool ignored = (tgt == ignore_index);
+  const int nvec = V >> 3;  // V is a multiple of 8 (checked on the host)
+  const int tloc = (int)(tgt - vocab_start);
+
+  float cache[CACHED ? kXentMaxVec : 1][8];
+  float mx = -INFINITY;
+  float sum = 0.f, lse = 0.f;
+
+  if (MODE != XENT_GRAD) {
+    if (ignored && MODE == XENT_FUSED) {
+      // Ignored rows contribute no loss and a zero gradient.
+      if (threadIdx.x == 0) loss_rows[row] = 0.f;
+      if (write_grad) {
+        float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = threadIdx.x; i < nvec; i += kXentThreads) store8(lr + i * 8, z);
+      }
+      return;
+    }
+    if (CACHED) {
+#pragma unroll
+      for (int k = 0; k < kXentMaxVec; ++k) {
+        const int i = threadIdx.x + k * kXentThreads;
+        if (i < nvec) {
+          load8(lr + i * 8, cache[k]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, cache[k][j]);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < nvec; i += kXentThreads) {
+        float x[8];
+        load8(lr + i * 8, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, x[j]);
+      }
+    }
+    mx = block_max(mx, red);
+    if (CACHED) {
+#pragma unroll
+      for (int k = 0; k < kXentMaxVec; ++k) {
+        const int i = threadIdx.x + k * kXentThreads;
+        if (i < nvec) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum += __expf(cache[k][j] - mx);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < nvec; i += kXentThreads) {
+        float x[8];
+        load8(lr + i * 8, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += __expf(x[j] - mx);
+      }
+    }
+    sum = block_sum(sum, red);
+    if (MODE == XENT_STATS) {
+      if (threadIdx.x == 0) {
+        row_max[row] = mx;
+        row_sum[row] = sum;
+        float t = 0.f;
+        if (!ignored && tloc >= 0 && tloc < V) t = Cvt<T>::ld(lr + tloc);
+        row_tgt[row] = t;
+      }
+      return;
+    }
+    lse = mx + __logf(sum);
+    if (threadIdx.x == 0) loss_rows[row] = lse - Cvt<T>::ld(lr + tloc);
+  } else {
+    lse = lse_in[row];
+    if (threadIdx.x == 0 && loss_rows != nullptr) {
+      // In the sharded case the caller supplies the all-reduced target logit through row_tgt.
+      loss_rows[row] = ignored ? 0.f : (lse - row_tgt[row]);
+    }
+  }
+
+  if (!write_grad) return;
+  const float scale = ignored ? 0.f : *grad_scale;
+  __syncthreads();  // every thread has read its logits before anybody overwrites (target read above)
+  if (CACHED && MODE == XENT_FUSED) {
+#pragma unroll
+    for (int k = 0; k < kXentMaxVec; ++k) {
+      const int i = threadIdx.x + k * kXentThreads;
+      if (i < nvec) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __expf(cache[k][j] - lse);
+          o[j] = (p - ((i * 8 + j) == tloc ? 1.f : 0.f)) * scale;
+        }
+        store8(lr + i * 8, o);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < nvec; i += kXentThreads) {
+      float x[8], o[8];
+      load8(lr + i * 8, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float p = __expf(x[j] - lse);
+        o[j] = (p - ((i * 8 + j) == tloc ? 1.f : 0.f)) * scale;
+      }
+      store8(lr + i * 8, o);
+    }
+  }
+}
+
+template <typename T>
+static void xent_launch(int mode, T* logits, const long long* targets, float* loss_rows, float* row_max,
+                        float* row_sum, float* row_tgt, const float* lse_in, const float* grad_scale, int rows,
+                        int V, int ld, int vocab_start, long long ignore_index, bool write_grad, hipStream_t st) {
+  const dim3 grid(rows), block(kXentThreads);
+  const bool cached = V <= kXentMaxVec * 8 * kXentThreads;
+#define DPA_X(MODE, C)                                                                                       \
+  hipLaunchKernelGGL((xent_kernel<T, MODE, C>), grid, block, 0, st, logits, targets, loss_rows, row_max, row_sum, \
+                     row_tgt, lse_in, grad_scale, V, ld, vocab_start, ignore_index, write_grad ? 1 : 0)
+  if (mode == XENT_FUSED) {
+    if (cached) DPA_X(XENT_FUSED, true); else DPA_X(XENT_FUSED, false);
+  } else if (mode == XENT_STATS) {
+    if (cached) DPA_X(XENT_STATS, true); else DPA_X(XENT_STATS, false);
+  } else {
+    DPA_X(XENT_GRAD, false);
+  }
+#undef DPA_X
+}
+
+void xent(int mode, void* logits, bool is_bf16, const long long* targets, float* loss_rows, float* row_max,
+          float* row_sum, float* row_tgt, const float* lse_in, const float* grad_scale, int rows, int V, int ld,
+          int vocab_start, long long ignore_index, bool write_grad, hipStream_t st) {
+  if (rows == 0) return;
+  if (is_bf16)
+    xent_launch<bf16_t>(mode, (bf16_t*)logits, targets, loss_rows, row_max, row_sum, row_tgt, lse_in, grad_scale,
+                        rows, V, ld, vocab_start, ignore_index, write_grad, st);
+  else
+    xent_launch<float>(mode, (float*)logits, targets, loss_rows, row_max, row_sum, row_tgt, lse_in, grad_scale,
+                       rows, V, ld, vocab_start, ignore_index, write_grad, st);
+}
+
+}  // namespace dpa

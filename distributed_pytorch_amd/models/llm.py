@@ -1,0 +1,590 @@
+"""The configurable decoder-only LLM.
+
+Same public surface and the same ``state_dict`` key schema as the reference model
+(reference: single-gpu/model.py:98-747): ``LLM(config)``, ``forward(idx, targets=None,
+kv_caches=None) -> (logits, loss, kv_caches)``, ``generate``, ``configure_optimizers``,
+``get_num_params``, attribute ``VAL_RUN``; attention in {mha, mqa, gqa, mla}, positions in
+{learn, sin, rope}, dense MLP or DeepSeek-style MoE, KV-cache decoding, activation
+recomputation. A checkpoint written from this model loads into the reference ``LLM`` with
+``strict=True`` and vice versa.
+
+What is different underneath:
+
+* every hot op goes through ``ops`` (HIP kernels on the GPU): fused embedding gather,
+  LayerNorm with fused residual add, flash attention that reads the fused QKV projection in
+  place and is GQA-native, exact-erf GELU / SwiGLU kernels, fused lm_head + cross-entropy that
+  never materialises the logits;
+* the compute dtype is the parameter dtype (the engines in ``parallel/`` keep bf16 compute
+  copies of fp32 master weights in flat buffers); there is no autocast;
+* the residual stream is carried as ``(x, delta)`` so that each residual add is fused into
+  the next LayerNorm;
+* MLA is expressed as multi-query flash attention over the latent KV (absorbed projections)
+  instead of materialising ``(B, nh, T, T)`` scores;
+* MoE routes with one sort (no per-expert ``nonzero`` host round trips) and updates the
+  aux-free bias exactly once per training forward, also under activation recomputation;
+* cached decoding uses a bottom-right aligned causal mask (the reference's GQA path attends to
+  key 0 only when decoding from a cache).
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+import threading
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+from .. import ops
+from ..config import LLMconfig
+
+__all__ = ["LLM", "Block", "GQA", "NaiveMHLA", "FullMHLA", "Attention", "MLP", "Expert", "MoE"]
+
+_tls = threading.local()
+
+
+def _in_recompute() -> bool:
+    return getattr(_tls, "recompute", False)
+
+
+@contextlib.contextmanager
+def _recompute_scope():
+    prev = getattr(_tls, "recompute", False)
+    _tls.recompute = True
+    try:
+        yield
+    finally:
+        _tls.recompute = prev
+
+
+def _ckpt_contexts():
+    return contextlib.nullcontext(), _recompute_scope()
+
+
+def _drop(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    return F.dropout(x, p, training) if (p > 0.0 and training) else x
+
+
+# ---------------------------------------------------------------------------------------------
+class GQA(nn.Module):
+    """Grouped-query attention (MHA / MQA / GQA) with or without RoPE
+    (reference: single-gpu/model.py:98-155)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        if config.attn == "mha":
+            config.n_kv_heads = config.n_head
+        elif config.attn == "mqa":
+            config.n_kv_heads = 1
+        else:
+            assert config.n_head % config.n_kv_heads == 0, "n_head must be divisible by n_kv_heads"
+        assert config.n_embd % config.n_head == 0, "n_embd must be divisible by n_head"
+        self.config = config
+        self.head_size = config.n_embd // config.n_head
+        self.c_attn = nn.Linear(config.n_embd, config.n_embd + 2 * config.n_kv_heads * self.head_size)
+        self.c_proj = nn.Linear(config.n_embd, config.n_embd)
+        self.attn_dropout = nn.Dropout(config.dropout)   # kept for module-tree parity; unused like the reference's
+        self.resid_dropout = nn.Dropout(config.dropout)
+
+    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False):
+        B, T, C = x.shape
+        nh, nkv, hs = self.config.n_head, self.config.n_kv_heads, self.head_size
+        p_drop = self.config.dropout if self.training else 0.0
+        qkv = F.linear(x, self.c_attn.weight, self.c_attn.bias)
+        if rope is not None:
+            # rotate the q and k heads (contiguous leading part of the fused projection)
+            cos_t, sin_t, pos0 = rope
+            qk = ops.apply_rope(qkv[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, pos0)
+            qkv = torch.cat([qk.view(B, T, (nh + nkv) * hs), qkv[..., (nh + nkv) * hs:]], dim=-1)
+        if kv_cache is None and not self._want_cache():
+            y = ops.causal_self_attention_qkv(qkv, nh, nkv, dropout_p=p_drop)
+            new_cache = None
+        else:
+            q, k, v = ops.split_qkv(qkv, nh, nkv)
+            if kv_cache is not None:
+                past_k, past_v = kv_cache                      # (B, nkv, Tp, hs) views of (B, Tp, nkv, hs)
+                k = torch.cat((past_k.transpose(1, 2), k), dim=1)
+                v = torch.cat((past_v.transpose(1, 2), v), dim=1)
+            y = ops.causal_attention(q, k, v, dropout_p=p_drop)
+            new_cache = (k.transpose(1, 2), v.transpose(1, 2))  # reference cache shape (B, nkv, T, hs)
+        y = y.reshape(B, T, C)
+        y = _drop(F.linear(y, self.c_proj.weight, self.c_proj.bias), self.config.dropout, self.training)
+        return y, new_cache
+
+    def _want_cache(self) -> bool:
+        # The training / validation path never reads the returned cache; building it would only
+        # cost memory. Inference (eval mode outside a validation run) returns it.
+        return not self.training and not getattr(self, "_val_run", False)
+
+
+def _mla_attention(q_eff, k_eff, v_lat, scale, dropout_p):
+    """Multi-query attention over latent keys/values: q_eff [B,T,nh,Dk], k_eff [B,Tk,1,Dk],
+    v_lat [B,Tk,1,Dv] -> [B,T,nh,Dv]. Uses the flash kernel when Dk is a supported head size
+    (V is zero-padded to Dk), otherwise the eager path."""
+    Dk, Dv = q_eff.shape[-1], v_lat.shape[-1]
+    if q_eff.is_cuda and q_eff.dtype == torch.bfloat16 and Dk in (64, 128) and dropout_p == 0.0:
+        v_pad = v_lat if Dv == Dk else F.pad(v_lat, (0, Dk - Dv))
+        return ops.causal_attention(q_eff.contiguous(), k_eff.contiguous(), v_pad.contiguous(), scale)[..., :Dv]
+    return ops.causal_attention_eager(q_eff, k_eff, v_lat, scale, dropout_p)
+
+
+class NaiveMHLA(nn.Module):
+    """Multi-head latent attention without RoPE (reference: single-gpu/model.py:157-235)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0, "num of heads must be a divisor of n_embd"
+        self.head_size = config.n_embd // config.n_head
+        self.config = config
+        self.W_dq = nn.Linear(config.n_embd, config.q_latent_dim, bias=False)
+        self.W_uq = nn.Linear(config.q_latent_dim, config.n_embd, bias=False)
+        self.W_dkv = nn.Linear(config.n_embd, config.kv_latent_dim, bias=False)
+        self.W_uk = nn.Linear(config.kv_latent_dim, config.n_embd, bias=False)
+        self.W_uv = nn.Linear(config.kv_latent_dim, config.n_embd, bias=False)
+        self.W_o = nn.Linear(config.n_embd, config.n_embd, bias=False)
+        self.dropout = nn.Dropout(config.dropout)
+        self.register_buffer("_k_absorbed_inference", None)
+        self.register_buffer("_v_absorbed_inference", None)
+
+    def _absorbed(self):
+        nh, n_kvl, hs = self.config.n_head, self.config.kv_latent_dim, self.head_size
+        # Same absorbed products as the reference (single-gpu/model.py:196-197), including its choice
+        # of folding W_dq^T W_uq^T into the key side: (nh, hs, n_kvl) and (nh, n_kvl, hs).
+        k_abs = (self.W_dq.weight.t() @ self.W_uq.weight.t() @ self.W_uk.weight).view(nh, hs, n_kvl)
+        v_abs = (self.W_uv.weight.t() @ self.W_o.weight.t()).view(n_kvl, nh, hs).transpose(0, 1)
+        return k_abs, v_abs
+
+    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False):
+        B, T, C = x.shape
+        nh, n_kvl, hs = self.config.n_head, self.config.kv_latent_dim, self.head_size
+        p_drop = self.config.dropout if self.training else 0.0
+        if self.training or VAL_RUN:
+            k_abs, v_abs = self._absorbed()
+        else:
+            if self._k_absorbed_inference is None or self._v_absorbed_inference is None:
+                with torch.no_grad():
+                    k_abs, v_abs = self._absorbed()
+                    self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
+            k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
+        new_c_kv = F.linear(x, self.W_dkv.weight)
+        c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache, new_c_kv], dim=1)
+        q = F.linear(F.linear(x, self.W_dq.weight), self.W_uq.weight).view(B, T, nh, hs)
+        q_eff = torch.einsum("bthd,hdl->bthl", q, k_abs.to(q.dtype))          # (B, T, nh, n_kvl)
+        ctx = _mla_attention(q_eff, c_kv.unsqueeze(2), c_kv.unsqueeze(2), 1.0 / math.sqrt(hs), p_drop)
+        y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
+        y = _drop(y, self.config.dropout, self.training)
+        return y, c_kv
+
+
+class FullMHLA(nn.Module):
+    """Multi-head latent attention with decoupled RoPE, DeepSeek-V2 style
+    (reference: single-gpu/model.py:237-345)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0, "num of heads must be a divisor of n_embd"
+        self.config = config
+        self.W_dq = nn.Linear(config.n_embd, config.q_latent_dim, False)
+        self.dropout = nn.Dropout(config.dropout)
+        self.head_size = config.n_embd // config.n_head
+        self.W_uq = nn.Linear(config.q_latent_dim, config.n_embd, False)
+        self.W_dkv = nn.Linear(config.n_embd, config.kv_latent_dim, False)
+        self.W_uk = nn.Linear(config.kv_latent_dim, config.n_embd, False)
+        self.W_uv = nn.Linear(config.kv_latent_dim, config.n_embd, False)
+        self.W_qr = nn.Linear(config.q_latent_dim, config.n_head * config.rope_head_dim, False)
+        self.W_kr = nn.Linear(config.n_embd, config.rope_head_dim, False)
+        self.W_o = nn.Linear(config.n_embd, config.n_embd, False)
+        self.register_buffer("_k_absorbed_inference", None, persistent=False)
+        self.register_buffer("_v_absorbed_inference", None, persistent=False)
+
+    def _absorbed(self):
+        nh, nlkv, hs, nlq = self.config.n_head, self.config.kv_latent_dim, self.head_size, self.config.q_latent_dim
+        # Same absorbed products as the reference (single-gpu/model.py:291-292): W_uq.weight is
+        # re-viewed (not transposed) as (nlq, nh, hs), exactly as the reference does, so that a
+        # checkpoint means the same function in both code bases. (nh, nlq, nlkv) and (nh, nlkv, hs).
+        k_abs = self.W_uq.weight.view(nlq, nh, hs).transpose(0, 1) @ self.W_uk.weight.view(nh, hs, nlkv)
+        v_abs = (self.W_uv.weight.t() @ self.W_o.weight.t()).view(nlkv, nh, hs).transpose(0, 1)
+        return k_abs, v_abs
+
+    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False):
+        B, T, C = x.shape
+        nh, nlkv = self.config.n_head, self.config.kv_latent_dim
+        hs, dhr = self.head_size, self.config.rope_head_dim
+        p_drop = self.config.dropout if self.training else 0.0
+        cos_t, sin_t, pos0 = rope
+        c_q = F.linear(x, self.W_dq.weight)                                   # (B, T, nlq)
+        if self.training or VAL_RUN:
+            k_abs, v_abs = self._absorbed()
+        else:
+            if self._k_absorbed_inference is None or self._v_absorbed_inference is None:
+                with torch.no_grad():
+                    k_abs, v_abs = self._absorbed()
+                    self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
+            k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
+        new_c_kv = F.linear(x, self.W_dkv.weight)
+        c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache["c_kv"], new_c_kv], dim=1)
+        k_r = ops.apply_rope(F.linear(x, self.W_kr.weight).view(B, T, 1, dhr), cos_t, sin_t, pos0)
+        k_r = k_r.transpose(1, 2)                                              # (B, 1, T, dhr): cache layout
+        if kv_cache is not None:
+            k_r = torch.cat([kv_cache["k_r"], k_r], dim=2)
+        q_r = ops.apply_rope(F.linear(c_q, self.W_qr.weight).view(B, T, nh, dhr), cos_t, sin_t, pos0)
+        q_nope = torch.einsum("btq,hql->bthl", c_q, k_abs.to(c_q.dtype))       # (B, T, nh, nlkv)
+        q_eff = torch.cat([q_nope, q_r], dim=-1)                               # (B, T, nh, nlkv + dhr)
+        k_eff = torch.cat([c_kv, k_r.squeeze(1)], dim=-1).unsqueeze(2)         # (B, Tk, 1, nlkv + dhr)
+        ctx = _mla_attention(q_eff, k_eff, c_kv.unsqueeze(2), 1.0 / math.sqrt(hs + dhr), p_drop)
+        y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
+        y = _drop(y, self.config.dropout, self.training)
+        return y, {"c_kv": c_kv, "k_r": k_r}
+
+
+class Attention(nn.Module):
+    """Routes to the configured attention (reference: single-gpu/model.py:347-363)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        self.config = config
+        if config.attn in ("mha", "mqa", "gqa"):
+            self.attn = GQA(config)
+        elif config.attn == "mla":
+            self.attn = NaiveMHLA(config) if config.pos_emb != "rope" else FullMHLA(config)
+        else:
+            raise ValueError(f"unknown attention {config.attn!r}")
+
+    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False):
+        if isinstance(self.attn, GQA):
+            self.attn._val_run = VAL_RUN
+        return self.attn(x, rope, kv_cache, VAL_RUN)
+
+
+# ---------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    """Feed-forward block, bias-free (reference: single-gpu/model.py:365-398)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        self.non_linearity = config.non_linearity.lower()
+        if self.non_linearity == "swiglu":
+            self.c_fc = nn.Linear(config.n_embd, 2 * config.up_dim, bias=False)
+        else:
+            self.c_fc = nn.Linear(config.n_embd, config.up_dim, bias=False)
+            self._act = ops.get_activation(self.non_linearity)
+        self.c_proj = nn.Linear(config.up_dim, config.n_embd, bias=False)
+        self.dropout = nn.Dropout(config.dropout)
+        self.p_drop = config.dropout
+
+    def forward(self, x):
+        h = F.linear(x, self.c_fc.weight)
+        h = ops.swiglu(h) if self.non_linearity == "swiglu" else self._act(h)
+        return _drop(F.linear(h, self.c_proj.weight), self.p_drop, self.training)
+
+
+class Expert(nn.Module):
+    """One expert; exists for the ``experts.{j}.expert.*`` key prefix
+    (reference: single-gpu/model.py:400-407)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        self.expert = MLP(config)
+
+    def forward(self, x):
+        return self.expert(x)
+
+
+class MoE(nn.Module):
+    """DeepSeekMoE layer: shared + routed experts, classic aux loss or aux-loss-free balancing
+    (reference: single-gpu/model.py:409-506).
+
+    ``dispatcher`` is a hook for expert parallelism: when set (see ``parallel/ep.py``) the routed
+    experts are evaluated through an all-to-all instead of locally."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        self.config = config
+        self.n_shared = config.n_shared
+        self.n_routed = config.n_exp - config.n_shared
+        self.n_act_routed = config.n_act - config.n_shared
+        assert self.n_act_routed > 0, "Number of active experts must be greater than shared experts"
+        self.experts = nn.ModuleList([Expert(config) for _ in range(config.n_exp)])
+        self.gate = nn.Linear(config.n_embd, self.n_routed, bias=False)
+        if config.aux_free:
+            self.register_buffer("expert_bias", torch.zeros(self.n_routed))
+        self.dispatcher = None
+
+    def route(self, x_flat):
+        """-> (topk_indices [N,k], topk_gates [N,k], aux_loss)."""
+        cfg = self.config
+        n_tokens = x_flat.shape[0]
+        router_logits = F.linear(x_flat, self.gate.weight).float()
+        if cfg.aux_free:
+            biased = router_logits + self.expert_bias.float()
+            _, topk_indices = torch.topk(biased, self.n_act_routed, dim=1)
+            topk_gates = F.softmax(torch.gather(router_logits, 1, topk_indices), dim=1)
+            with torch.no_grad():
+                fi = torch.bincount(topk_indices.flatten(), minlength=self.n_routed).float() / n_tokens
+                if self.training and not _in_recompute():
+                    self.expert_bias += (cfg.gamma * (1.0 / self.n_routed - fi)).to(self.expert_bias.dtype)
+            pi = F.softmax(router_logits, dim=1).mean(dim=0)
+            aux_loss = cfg.alpha * self.n_routed * torch.sum(pi * fi)
+        else:
+            pi = F.softmax(router_logits, dim=1).mean(dim=0)
+            topk_logits, topk_indices = torch.topk(router_logits, self.n_act_routed, dim=1)
+            with torch.no_grad():
+                fi = torch.bincount(topk_indices.flatten(), minlength=self.n_routed).float() / n_tokens
+            aux_loss = cfg.coeff * self.n_routed * torch.sum(pi * fi)
+            topk_gates = F.softmax(topk_logits, dim=1)
+        return topk_indices, topk_gates.to(x_flat.dtype), aux_loss
+
+    def routed_experts_local(self, x_flat, topk_indices, topk_gates):
+        """Sort the (token, slot) pairs by expert once, run every expert on its contiguous slice,
+        scale by the gate and scatter-add back. One host read of the per-expert counts replaces
+        the reference's per-expert ``nonzero``."""
+        N, k = topk_indices.shape
+        flat_e = topk_indices.reshape(-1)
+        order = torch.argsort(flat_e, stable=True)
+        tok = torch.div(order, k, rounding_mode="floor")
+        counts = torch.bincount(flat_e, minlength=self.n_routed).tolist()
+        xs = x_flat[tok]
+        gs = topk_gates.reshape(-1)[order].unsqueeze(1)
+        outs = []
+        start = 0
+        for i, c in enumerate(counts):
+            if c:
+                outs.append(self.experts[i + self.n_shared](xs[start:start + c]))
+            start += c
+        ys = torch.cat(outs, dim=0) * gs
+        return torch.zeros_like(x_flat).index_add_(0, tok, ys.to(x_flat.dtype))
+
+    def forward(self, x):
+        B, T, C = x.shape
+        x_flat = x.reshape(-1, C)
+        shared_output = None
+        for i in range(self.n_shared):
+            o = self.experts[i](x_flat)
+            shared_output = o if shared_output is None else shared_output + o
+        topk_indices, topk_gates, aux_loss = self.route(x_flat)
+        if self.dispatcher is not None:
+            routed = self.dispatcher(self, x_flat, topk_indices, topk_gates)
+        else:
+            routed = self.routed_experts_local(x_flat, topk_indices, topk_gates)
+        y = routed if shared_output is None else shared_output + routed
+        return y.view(B, T, C), aux_loss
+
+
+# ---------------------------------------------------------------------------------------------
+class Block(nn.Module):
+    """Pre-LN transformer block (reference: single-gpu/model.py:508-533; attention-only
+    recomputation as in multi-gpu/ddp/kaggle-ddp.py:526-542).
+
+    The residual stream is passed as ``(x, delta)``: the caller's pending residual update
+    ``delta`` is added inside this block's first LayerNorm kernel, and the block returns its own
+    pending update instead of adding it."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        self.is_moe = config.moe
+        self.act_recomp = config.act_recomp
+        self.attn = Attention(config)
+        self.ln1 = nn.LayerNorm(config.n_embd)
+        self.ln2 = nn.LayerNorm(config.n_embd)
+        if config.moe:
+            self.moe = MoE(config)
+        else:
+            self.mlp = MLP(config)
+
+    def forward(self, x, delta=None, rope=None, kv_cache=None, VAL_RUN=False):
+        if delta is None:
+            h = ops.layer_norm(x, self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        else:
+            x, h = ops.add_layer_norm(x, delta, self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        if self.act_recomp and self.training and kv_cache is None:
+            attn_out, new_cache = checkpoint(self.attn, h, rope, kv_cache, VAL_RUN, use_reentrant=False,
+                                             context_fn=_ckpt_contexts)
+        else:
+            attn_out, new_cache = self.attn(h, rope, kv_cache, VAL_RUN)
+        x, h2 = ops.add_layer_norm(x, attn_out, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+        if self.is_moe:
+            out, aux_loss = self.moe(h2)
+        else:
+            out, aux_loss = self.mlp(h2), 0.0
+        return x, out, new_cache, aux_loss
+
+
+# ---------------------------------------------------------------------------------------------
+class LLM(nn.Module):
+    """The language model (reference: single-gpu/model.py:535-747)."""
+
+    def __init__(self, config: LLMconfig):
+        super().__init__()
+        self.config = config
+        self.head_size = config.n_embd // config.n_head
+        self.tkn_emb = nn.Embedding(config.vocab_size, config.n_embd)
+        if config.pos_emb == "learn":
+            self.pos_emb = nn.Embedding(config.block_size, config.n_embd)
+        elif config.pos_emb == "sin":
+            pe = torch.zeros(config.block_size, config.n_embd)
+            position = torch.arange(0, config.block_size, dtype=torch.float).unsqueeze(1)
+            div_term = torch.exp(torch.arange(0, config.n_embd, 2).float() * (-math.log(10000.0) / config.n_embd))
+            pe[:, 0::2] = torch.sin(position * div_term)
+            pe[:, 1::2] = torch.cos(position * div_term)
+            self.register_buffer("pos_emb", pe)
+        elif config.pos_emb == "rope":
+            d = config.rope_head_dim if config.attn == "mla" else self.head_size
+            assert d % 2 == 0, "head dimension must be even"
+            cos_t, sin_t = ops.rope_tables(config.block_size, d)
+            # complex table kept only so that the state-dict key set equals the reference's
+            self.register_buffer("freqs_cis", torch.complex(cos_t, sin_t))
+            self.register_buffer("rope_cos", cos_t, persistent=False)
+            self.register_buffer("rope_sin", sin_t, persistent=False)
+        self.transformer = nn.ModuleDict(dict(
+            drop=nn.Dropout(config.dropout),
+            h=nn.ModuleList([Block(config) for _ in range(config.n_layer)]),
+            ln_f=nn.LayerNorm(config.n_embd)))
+        self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False)
+        self.tkn_emb.weight = self.lm_head.weight  # weight tying
+        self.apply(self._init_weights)
+        self.VAL_RUN = False
+        self.materialize_logits = False   # True: also return [B, T, V] logits when targets are given
+        self.loss_chunk_rows = 8192
+        self.print_act_recomp = config.act_recomp
+        self.print_fused_adamw = True
+        self._pos_cache = None
+
+    # ---- construction helpers -------------------------------------------------------------
+    def _init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)
+            if module.bias is not None:
+                torch.nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.Embedding):
+            torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)
+
+    def get_num_params(self):
+        """(total, active) parameter counts (reference: single-gpu/model.py:588-617)."""
+        n_params = sum(p.numel() for p in self.parameters())
+        active = self.tkn_emb.weight.numel()
+        if self.config.pos_emb == "learn":
+            active += self.pos_emb.weight.numel()
+        active += sum(p.numel() for p in self.transformer.ln_f.parameters())
+        for block in self.transformer.h:
+            active += sum(p.numel() for p in block.attn.parameters())
+            active += sum(p.numel() for p in block.ln1.parameters())
+            active += sum(p.numel() for p in block.ln2.parameters())
+            if block.is_moe:
+                active += sum(p.numel() for p in block.moe.gate.parameters())
+                for i in range(block.moe.n_shared):
+                    active += sum(p.numel() for p in block.moe.experts[i].parameters())
+                if block.moe.n_routed > 0:
+                    per = sum(p.numel() for p in block.moe.experts[block.moe.n_shared].parameters())
+                    active += block.moe.n_act_routed * per
+            else:
+                active += sum(p.numel() for p in block.mlp.parameters())
+        return n_params, active
+
+    def param_groups(self, weight_decay: float):
+        """Decay every tensor with >= 2 dims, nothing else (reference: single-gpu/model.py:619-629)."""
+        params = [p for p in self.parameters() if p.requires_grad]
+        return [{"params": [p for p in params if p.dim() >= 2], "weight_decay": weight_decay},
+                {"params": [p for p in params if p.dim() < 2], "weight_decay": 0.0}]
+
+    def configure_optimizers(self, weight_decay, learning_rate, device=None):
+        """Stock AdamW over the module's own parameters (CPU / un-wrapped use). The engines in
+        ``parallel/`` replace this with the flat fused optimizer."""
+        groups = self.param_groups(weight_decay)
+        dev = str(device) if device is not None else str(next(self.parameters()).device)
+        try:
+            opt = torch.optim.AdamW(groups, lr=learning_rate, fused=("cuda" in dev))
+        except Exception:
+            self.print_fused_adamw = False
+            opt = torch.optim.AdamW(groups, lr=learning_rate)
+        return opt
+
+    # ---- forward --------------------------------------------------------------------------
+    def _start_pos(self, kv_caches) -> int:
+        if kv_caches is None or kv_caches[0] is None:
+            return 0
+        c = kv_caches[0]
+        if self.config.attn in ("mha", "mqa", "gqa"):
+            return c[0].shape[-2]
+        return c["c_kv"].shape[1] if self.config.pos_emb == "rope" else c.shape[1]
+
+    def _pos_table(self, dtype, device):
+        """Position table in the compute dtype (learned weight, or the sinusoidal buffer cast once)."""
+        if self.config.pos_emb == "learn":
+            return self.pos_emb.weight
+        if self.config.pos_emb == "sin":
+            pc = self._pos_cache
+            if pc is None or pc.dtype != dtype or pc.device != device:
+                pc = self._pos_cache = self.pos_emb.to(device=device, dtype=dtype)
+            return pc
+        return None
+
+    def forward(self, idx: torch.Tensor, targets=None, kv_caches=None):
+        cfg = self.config
+        B, T = idx.shape
+        start_pos = self._start_pos(kv_caches)
+        wte = self.lm_head.weight
+        x = ops.embedding(idx, wte, self._pos_table(wte.dtype, wte.device), start_pos)
+        rope = (self.rope_cos, self.rope_sin, start_pos) if cfg.pos_emb == "rope" else None
+        x = _drop(x, cfg.dropout, self.training)
+        if kv_caches is None:
+            kv_caches = [None] * cfg.n_layer
+        new_caches = []
+        total_aux = 0.0
+        delta = None
+        for i, block in enumerate(self.transformer.h):
+            x, delta, cache, aux = block(x, delta, rope, kv_caches[i], self.VAL_RUN)
+            new_caches.append(cache)
+            total_aux = total_aux + aux
+        ln_f = self.transformer.ln_f
+        if delta is None:
+            x = ops.layer_norm(x, ln_f.weight, ln_f.bias, ln_f.eps)
+        else:
+            _, x = ops.add_layer_norm(x, delta, ln_f.weight, ln_f.bias, ln_f.eps)
+        if targets is not None:
+            logits = None
+            if self.materialize_logits:
+                logits = F.linear(x, wte)
+                main_loss = ops.cross_entropy(logits, targets)
+            else:
+                main_loss = ops.linear_cross_entropy(x, wte, targets, chunk_rows=self.loss_chunk_rows)
+            loss = main_loss + total_aux / cfg.n_layer
+        else:
+            logits = F.linear(x[:, [-1], :], wte)
+            loss = None
+        return logits, loss, new_caches
+
+    # ---- generation -----------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, idx: torch.Tensor, max_new_tokens: int, temperature: float = 1.0, topk: int | None = None):
+        """KV-cache sampling with a sliding window of ``block_size - 1`` cached positions
+        (reference: single-gpu/model.py:699-747)."""
+        was_training = self.training
+        self.eval()
+        cfg = self.config
+        kv_caches = [None] * cfg.n_layer
+        for i in range(max_new_tokens):
+            inp = (idx if idx.size(1) <= cfg.block_size else idx[:, -cfg.block_size:]) if i == 0 else idx[:, -1:]
+            if kv_caches[0] is not None and self._start_pos(kv_caches) >= cfg.block_size:
+                keep = cfg.block_size - 1
+                for li in range(cfg.n_layer):
+                    c = kv_caches[li]
+                    if cfg.attn in ("mha", "mqa", "gqa"):
+                        kv_caches[li] = (c[0][..., -keep:, :], c[1][..., -keep:, :])
+                    elif cfg.pos_emb == "rope":
+                        kv_caches[li] = {"c_kv": c["c_kv"][:, -keep:, :], "k_r": c["k_r"][:, :, -keep:, :]}
+                    else:
+                        kv_caches[li] = c[:, -keep:, :]
+            logits, _, kv_caches = self.forward(inp, kv_caches=kv_caches)
+            logits = logits[:, -1, :].float()
+            if temperature > 0:
+                logits = logits / temperature
+            if topk is not None:
+                v, _ = torch.topk(logits, min(topk, logits.size(-1)))
+                logits[logits < v[:, [-1]]] = -float("inf")
+            probs = F.softmax(logits, dim=-1)
+            idx_next = torch.multinomial(probs, num_samples=1)
+            idx = torch.cat((idx, idx_next), dim=1)
+        if was_training:
+            self.train()
+        return idx

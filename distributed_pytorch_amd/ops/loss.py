@@ -1,0 +1,175 @@
+"""Cross-entropy and the fused lm_head + cross-entropy.
+
+``cross_entropy(logits, targets)``: mean NLL over targets != ignore_index. On the GPU the
+softmax statistics, the loss and the gradient are produced by one kernel that overwrites the
+logits with d(loss)/d(logits), so no fp32 probability tensor ever exists.
+
+``linear_cross_entropy(x, w, targets)``: loss of ``lm_head`` + cross-entropy without keeping
+the ``[B*T, V]`` logits: rows are processed in chunks; for each chunk the logits GEMM, the
+cross-entropy kernel and (when training) the two gradient GEMMs ``dx = dlogits @ w`` and
+``dw += dlogits^T @ x`` run back to back while the chunk is still cache-resident. The
+backward pass only rescales the stored gradients by the incoming scalar.
+
+``vocab_parallel_cross_entropy``: the same loss with the vocabulary sharded over a process
+group (all-reduce of max / sum-exp / target logit between the two kernel halves).
+
+Reference behaviour: ``F.cross_entropy(logits.view(-1, V), targets.view(-1), ignore_index=-1)``
+on the full fp32/amp logits (reference: single-gpu/model.py:687-692).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .._ext import ops, use_hip
+
+IGNORE_INDEX = -1
+
+
+def _hip_ok(logits: torch.Tensor, targets: torch.Tensor) -> bool:
+    return (use_hip(logits, targets) and logits.dtype in (torch.bfloat16, torch.float32)
+            and logits.shape[-1] % 8 == 0)
+
+
+def _grad_scale(targets: torch.Tensor, ignore_index: int) -> torch.Tensor:
+    n_valid = (targets != ignore_index).sum().clamp_min(1)
+    return (1.0 / n_valid.float()).reshape(1)
+
+
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        need_grad = logits.requires_grad
+        work = logits.contiguous()
+        if need_grad and work.data_ptr() == logits.data_ptr():
+            work = work.clone()  # the kernel overwrites its input; never clobber the caller's logits
+        gs = _grad_scale(targets, ignore_index)
+        loss_rows = ops().xent_fused(work, targets.contiguous(), gs, ignore_index, need_grad)
+        if need_grad:
+            ctx.save_for_backward(work)
+        return loss_rows.sum() * gs[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g.to(dlogits.dtype), None, None
+
+
+def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = IGNORE_INDEX) -> torch.Tensor:
+    logits2 = logits.reshape(-1, logits.shape[-1])
+    targets1 = targets.reshape(-1)
+    if _hip_ok(logits2, targets1):
+        return _XentFn.apply(logits2, targets1, ignore_index)
+    return F.cross_entropy(logits2.float(), targets1, ignore_index=ignore_index)
+
+
+class _LinearXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, targets, ignore_index, chunk_rows):
+        N, C = x.shape
+        V = w.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1]
+        train = need_dx or need_dw
+        gs = _grad_scale(targets, ignore_index)
+        loss_acc = torch.zeros((), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if need_dx else None
+        dw = None
+        logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
+        for r0 in range(0, N, chunk_rows):
+            r1 = min(N, r0 + chunk_rows)
+            xc = x[r0:r1]
+            lg = logits[: r1 - r0]
+            torch.mm(xc, w.t(), out=lg)
+            loss_rows = ops().xent_fused(lg, targets[r0:r1], gs, ignore_index, train)
+            loss_acc += loss_rows.sum()
+            if need_dx:
+                torch.mm(lg, w, out=dx[r0:r1])
+            if need_dw:
+                if dw is None:
+                    dw = torch.mm(lg.t(), xc)
+                else:
+                    dw.addmm_(lg.t(), xc)
+        ctx.save_for_backward(dx, dw)
+        return loss_acc * gs[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, dw = ctx.saved_tensors
+        if dx is not None:
+            dx = dx.mul_(g.to(dx.dtype))
+        if dw is not None:
+            dw = dw.mul_(g.to(dw.dtype))
+        return dx, dw, None, None, None
+
+
+def linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor,
+                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 8192) -> torch.Tensor:
+    """Mean cross-entropy of ``x @ w.T`` against ``targets`` (``x [N, C]``, ``w [V, C]``)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    t1 = targets.reshape(-1)
+    if use_hip(x2, w, t1) and x2.dtype == w.dtype and x2.dtype in (torch.bfloat16, torch.float32) \
+            and w.shape[0] % 8 == 0:
+        return _LinearXentFn.apply(x2.contiguous(), w, t1.contiguous(), ignore_index, int(chunk_rows))
+    return F.cross_entropy(F.linear(x2, w).float(), t1, ignore_index=ignore_index)
+
+
+# ---------------------------------------------------------------------------------------------
+class _VocabParallelXentFn(torch.autograd.Function):
+    """logits_local [N, V/W] holds columns [vocab_start, vocab_start + V/W) of the full logits."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, vocab_start, group, ignore_index):
+        need_grad = logits.requires_grad
+        gs = _grad_scale(targets, ignore_index)
+        if _hip_ok(logits, targets):
+            work = logits.contiguous()
+            if need_grad and work.data_ptr() == logits.data_ptr():
+                work = work.clone()
+            mx, sm, tg = ops().xent_stats(work, targets, vocab_start, ignore_index)
+        else:
+            work = logits.float()
+            mx = work.max(dim=1).values
+            sm = torch.exp(work - mx[:, None]).sum(dim=1)
+            loc = targets - vocab_start
+            inr = (loc >= 0) & (loc < work.shape[1]) & (targets != ignore_index)
+            tg = torch.where(inr, work.gather(1, loc.clamp(0, work.shape[1] - 1)[:, None])[:, 0],
+                             torch.zeros_like(mx))
+        gmx = mx.clone()
+        dist.all_reduce(gmx, op=dist.ReduceOp.MAX, group=group)
+        sm = sm * torch.exp(mx - gmx)
+        packed = torch.stack([sm, tg])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        lse = gmx + torch.log(packed[0])
+        tgt_logit = packed[1].contiguous()
+        valid = targets != ignore_index
+        if _hip_ok(logits, targets):
+            loss_rows = ops().xent_grad(work, targets, lse.contiguous(), tgt_logit, gs, vocab_start, ignore_index,
+                                        need_grad)
+            dlogits = work
+        else:
+            loss_rows = torch.where(valid, lse - tgt_logit, torch.zeros_like(lse))
+            dlogits = None
+            if need_grad:
+                p = torch.exp(work - lse[:, None])
+                loc = targets - vocab_start
+                inr = (loc >= 0) & (loc < work.shape[1]) & valid
+                rows = torch.nonzero(inr).squeeze(1)
+                p[rows, loc[rows]] -= 1.0
+                p = p * (valid[:, None].to(p.dtype) * gs[0])
+                dlogits = p.to(logits.dtype)
+        if need_grad:
+            ctx.save_for_backward(dlogits)
+        return loss_rows.sum() * gs[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g.to(dlogits.dtype), None, None, None, None
+
+
+def vocab_parallel_cross_entropy(logits_local: torch.Tensor, targets: torch.Tensor, vocab_start: int,
+                                 group=None, ignore_index: int = IGNORE_INDEX) -> torch.Tensor:
+    return _VocabParallelXentFn.apply(logits_local.reshape(-1, logits_local.shape[-1]), targets.reshape(-1),
+                                      int(vocab_start), group, ignore_index)

@@ -1,0 +1,64 @@
+"""LayerNorm with optional fused residual add (HIP on the GPU, eager on the CPU).
+
+``layer_norm(x, w, b)``                -> y
+``add_layer_norm(x, r, w, b)``         -> (x + r, LN(x + r))   one pass over memory
+
+Reference behaviour: ``nn.LayerNorm(C)`` with eps 1e-5, affine weight and bias
+(reference: single-gpu/model.py:514-515,557).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .._ext import ops, use_hip
+
+_MAX_HIP_COLS = 4096
+
+
+def _hip_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    C = x.shape[-1]
+    return (use_hip(x, w) and C % 8 == 0 and C <= _MAX_HIP_COLS and x.dtype == w.dtype
+            and x.dtype in (torch.bfloat16, torch.float32))
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, w, b, eps):
+        xc = x.contiguous()
+        rc = res.contiguous() if res is not None else None
+        y, s, mean, rstd = ops().layernorm_fwd(xc, rc, w, b, eps)
+        ln_in = s if res is not None else xc
+        ctx.save_for_backward(ln_in, w, mean, rstd)
+        ctx.has_res = res is not None
+        if res is not None:
+            return s, y
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ln_in, w, mean, rstd = ctx.saved_tensors
+        if ctx.has_res:
+            ds, dy = grads
+            if dy is None:
+                return ds, ds, None, None, None
+            dres = ds.contiguous() if ds is not None else None
+            dx, dw, db = ops().layernorm_bwd(dy.contiguous(), ln_in, w, mean, rstd, dres)
+            return dx, dx, dw, db, None
+        (dy,) = grads
+        dx, dw, db = ops().layernorm_bwd(dy.contiguous(), ln_in, w, mean, rstd, None)
+        return dx, None, dw, db, None
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    if _hip_ok(x, w):
+        return _LayerNormFn.apply(x, None, w, b, eps)
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def add_layer_norm(x: torch.Tensor, r: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    """Returns ``(x + r, layer_norm(x + r))``."""
+    if _hip_ok(x, w) and r.dtype == x.dtype:
+        return _LayerNormFn.apply(x, r, w, b, eps)
+    s = x + r
+    return s, F.layer_norm(s, (s.shape[-1],), w, b, eps)

@@ -1,0 +1,277 @@
+"""Training engines: the model + flat parameter storage + fused optimizer + gradient sync.
+
+``Engine`` is the single-process form; ``parallel/ddp.py`` and ``parallel/zero.py`` subclass
+it and only override *where gradients are reduced* and *which element range this rank
+updates*; ``parallel/fsdp.py`` replaces the storage model (sharded parameters).
+
+Lifecycle of one optimizer step (mirrors the reference loop, single-gpu/train.py:320-352):
+
+    engine.zero_grad()
+    for micro_step in range(accum):
+        engine.require_backward_grad_sync = (micro_step == accum - 1)
+        _, loss, _ = engine(x, y);  (loss / accum).backward()
+    engine.clip_grad_norm_(max_norm)      # device-side norm; no host sync
+    engine.step(lr)                       # fused AdamW (+ clip, + overflow skip) on flat state
+
+Parameters are bf16 views of flat buffers on the GPU (fp32 on the CPU); the fp32 master
+weights live in the optimizer. ``state_dict()`` returns fp32 tensors under the reference's
+key schema whatever the sharding.
+"""
+from __future__ import annotations
+
+import contextlib
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import comm
+from .flat import FlatAdamW, FlatGroup, plan_groups
+
+
+def resolve_dtype(name: str, device: torch.device) -> torch.dtype:
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("fp32", "float32"):
+        return torch.float32
+    return torch.bfloat16 if device.type == "cuda" else torch.float32
+
+
+class _OptimizerFacade:
+    """The slice of the torch optimizer interface the reference loop uses
+    (``param_groups[i]['lr']``, ``zero_grad``, ``step``)."""
+
+    def __init__(self, engine: "Engine", lr: float):
+        self.engine = engine
+        self.param_groups = [{"lr": lr, "weight_decay": engine.weight_decay},
+                             {"lr": lr, "weight_decay": 0.0}]
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.engine.zero_grad()
+
+    def step(self):
+        self.engine.step(self.param_groups[0]["lr"])
+
+    def state_dict(self):
+        return self.engine.optimizer_state_dict()
+
+    def load_state_dict(self, sd):
+        self.engine.load_optimizer_state_dict(sd)
+
+
+class Engine(nn.Module):
+    name = "single"
+
+    def __init__(self, model: nn.Module, weight_decay: float = 0.1, lr: float = 3e-4, betas=(0.9, 0.999),
+                 eps: float = 1e-8, dtype: str = "auto", bucket_mb: float = 48.0, device=None, group=None):
+        super().__init__()
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        self.param_dtype = resolve_dtype(dtype, self.device)
+        self.module = model.to(self.device)
+        self.group = group
+        self.world = comm.world_size(group)
+        self.rank = comm.get_rank(group)
+        self.weight_decay = weight_decay
+        self.betas, self.eps = betas, eps
+        self.bucket_mb = bucket_mb
+        self.require_backward_grad_sync = True
+        self.step_count = 0
+        self._max_norm = 0.0
+        self._norm2 = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._have_norm = False
+        self._sync_initial_state()
+        self._build_storage()
+        self.optimizer = _OptimizerFacade(self, lr)
+
+    # ---- construction ---------------------------------------------------------------------
+    def _sync_initial_state(self):
+        """Every rank starts from rank 0's weights and buffers (seeds differ per rank)."""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + [b for b in self.module.buffers() if b is not None]:
+                if t.is_complex():
+                    v = torch.view_as_real(t.data)
+                    comm.broadcast(v, 0, self.group)
+                else:
+                    comm.broadcast(t.data, 0, self.group)
+
+    def _bucket_elems(self) -> int:
+        return int(self.bucket_mb * 1024 * 1024 / torch.empty((), dtype=self.param_dtype).element_size())
+
+    def _pad_multiple(self) -> int:
+        return 8 * self.world
+
+    def _build_storage(self):
+        plan = plan_groups(self.module, self._bucket_elems())
+        self.groups = [FlatGroup(np_, self.param_dtype, self.device, self._pad_multiple(), self.weight_decay, name)
+                       for name, np_ in plan]
+        self.optims = [FlatAdamW(g, *self._opt_range(g), betas=self.betas, eps=self.eps) for g in self.groups]
+        for g in self.groups:
+            g.drop_init()
+
+    def _opt_range(self, g: FlatGroup):
+        return 0, g.numel
+
+    # The reference trainers set ``VAL_RUN`` on whatever wrapper they hold
+    # (single-gpu/train.py:283); forward it to the real module.
+    @property
+    def VAL_RUN(self):
+        return self.module.VAL_RUN
+
+    @VAL_RUN.setter
+    def VAL_RUN(self, v):
+        self.module.VAL_RUN = v
+
+    # ---- forward / backward ---------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        self._pre_forward()
+        return self.module(*args, **kwargs)
+
+    def _pre_forward(self):
+        pass
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        prev = self.require_backward_grad_sync
+        self.require_backward_grad_sync = False
+        try:
+            yield
+        finally:
+            self.require_backward_grad_sync = prev
+
+    def zero_grad(self, set_to_none: bool = True):
+        for g in self.groups:
+            g.zero_grad()
+        self._have_norm = False
+
+    # ---- gradient sync hooks for subclasses -----------------------------------------------
+    def finish_grad_sync(self):
+        """Block the compute stream until every gradient collective has landed."""
+
+    def _grad_mul(self) -> float:
+        return 1.0
+
+    def _norm_ranges(self):
+        return None
+
+    def _reduce_norm(self):
+        pass
+
+    # ---- clipping + step ------------------------------------------------------------------
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """Record the clip threshold and compute the global gradient norm on the device. The
+        scaling itself happens inside the AdamW kernel. Returns the norm as a device tensor."""
+        self.finish_grad_sync()
+        self._max_norm = float(max_norm)
+        self._compute_norm()
+        return self._norm2.sqrt() * abs(self._grad_mul())
+
+    def _compute_norm(self):
+        from .flat import grad_norm_sq
+        grad_norm_sq(self._norm_grads(), self._norm2, None)
+        self._reduce_norm()
+        self._have_norm = True
+
+    def _norm_grads(self):
+        return self.groups
+
+    def step(self, lr: float | None = None):
+        self.finish_grad_sync()
+        if lr is None:
+            lr = self.optimizer.param_groups[0]["lr"]
+        if not self._have_norm:
+            self._compute_norm()   # also provides the overflow check
+        self.step_count += 1
+        self._apply_updates(float(lr))
+        self._have_norm = False
+        self._post_step()
+
+    def _apply_updates(self, lr: float):
+        for g, o in zip(self.groups, self.optims):
+            o.step(g.grad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
+                   self._grad_mul())
+
+    def _post_step(self):
+        self._sync_moe_bias()
+
+    def _sync_moe_bias(self):
+        """Average the aux-free MoE routing biases over the data-parallel ranks, i.e. balance on
+        the global expert load. (DDP in the reference re-broadcasts rank 0's buffer each forward,
+        so only rank 0's load statistics survive there.)"""
+        if self.world == 1:
+            return
+        biases = [b for n, b in self.module.named_buffers() if n.endswith("expert_bias")]
+        if not biases:
+            return
+        flat = torch.cat([b.reshape(-1).float() for b in biases])
+        comm.all_reduce(flat, group=self.group)
+        flat /= self.world
+        off = 0
+        for b in biases:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+    # ---- reference-compatible helpers -----------------------------------------------------
+    def configure_optimizers(self, weight_decay=None, learning_rate=None, device=None):
+        if learning_rate is not None:
+            for pg in self.optimizer.param_groups:
+                pg["lr"] = learning_rate
+        return self.optimizer
+
+    def get_num_params(self):
+        return self.module.get_num_params()
+
+    # ---- checkpoint state -----------------------------------------------------------------
+    def _full_master(self, gi: int) -> torch.Tensor:
+        """fp32 master weights of a whole group (gathered if sharded)."""
+        return self.optims[gi].master
+
+    def state_dict(self, *args, **kwargs):  # noqa: D401 - torch signature
+        """fp32 ``state_dict`` of the wrapped model in the reference's key schema."""
+        sd = OrderedDict()
+        by_param = {}
+        for gi, g in enumerate(self.groups):
+            full = self._full_master(gi)
+            for s in g.slots:
+                by_param[id(s.param)] = full[s.offset:s.offset + s.numel].view(s.shape).detach().clone()
+        raw = self.module.state_dict()
+        params = dict(self.module.named_parameters(remove_duplicate=False))
+        for k, v in raw.items():
+            p = params.get(k)
+            sd[k] = by_param[id(p)] if p is not None and id(p) in by_param else v.detach().clone()
+        return sd
+
+    def load_model_state(self, sd: dict):
+        """Load a reference-schema fp32 state dict into master + compute copies."""
+        params = dict(self.module.named_parameters(remove_duplicate=False))
+        with torch.no_grad():
+            for gi, g in enumerate(self.groups):
+                o = self.optims[gi]
+                for s in g.slots:
+                    key = next(k for k, p in params.items() if p is s.param and k in sd)
+                    src = sd[key].to(self.device).reshape(-1)
+                    g.data[s.offset:s.offset + s.numel].copy_(src)
+                    lo, hi = max(s.offset, o.lo), min(s.offset + s.numel, o.hi)
+                    if hi > lo:
+                        o.master[lo - o.lo:hi - o.lo].copy_(src[lo - s.offset:hi - s.offset].float())
+            for k, b in self.module.named_buffers():
+                if k in sd and b is not None:
+                    b.copy_(sd[k].to(b.device))
+
+    def optimizer_state_dict(self):
+        return {"step": self.step_count, "rank": self.rank, "world": self.world,
+                "groups": [o.state_dict() for o in self.optims]}
+
+    def load_optimizer_state_dict(self, sd):
+        assert sd["world"] == self.world, "resume with a different world size is not supported"
+        self.step_count = sd["step"]
+        for o, s in zip(self.optims, sd["groups"]):
+            o.load_state_dict(s)
+        with torch.no_grad():   # refresh the compute copies from the restored master weights
+            self._refresh_params_from_master()
+
+    def _refresh_params_from_master(self):
+        for g, o in zip(self.groups, self.optims):
+            g.data[o.lo:o.hi].copy_(o.master)

@@ -1,0 +1,203 @@
+"""The one training loop behind every entry point (single GPU, DDP, ZeRO-1/2, FSDP).
+
+Loop structure, LR schedule, evaluation and log lines follow the reference
+(reference: single-gpu/train.py:263-372, multi-gpu/ddp/train.py:270-342,
+multi-gpu/fsdp/kaggle-fsdp.py:1098-1139). Differences:
+
+* bf16 compute with fp32 master weights and no gradient scaler (the reference's multi-GPU
+  scripts hard-code fp16 + GradScaler); non-finite gradients skip the step inside the fused
+  optimizer;
+* the loss is read back to the host every ``sync_loss_every`` steps instead of every micro-step;
+* each step line also carries tokens/s and MFU; ``--metrics_jsonl`` mirrors it to a file;
+* the CPU path works (the reference's CPU path crashes on ``scaler.scale``);
+* data shards are deterministic per rank; rank 0 alone prepares synthetic data;
+* ``--save_model`` works for every strategy (state gathered to rank 0 in the reference key
+  schema); ``--save_interval`` / ``--resume`` add restartable training.
+"""
+from __future__ import annotations
+
+import math
+import os
+from time import perf_counter
+
+import torch
+
+from .checkpoint import load_resume, save_reference_checkpoint, save_resume
+from .config import LLMconfig, Trainconfig
+from .data import DataLoader, ensure_synthetic, resolve_data_dir
+from .models.llm import LLM
+from .parallel import comm
+from .utils.metrics import JsonlSink, PEAK_BF16_DENSE_FLOPS, mfu, model_flops_per_token
+from .utils.profiling import PhaseTimer
+
+
+def get_lr(it: int, tc: Trainconfig) -> float:
+    """Linear warm-up then cosine decay to 10 % (reference: single-gpu/train.py:263-278)."""
+    max_lr = tc.learning_rate
+    min_lr = max_lr * 0.1
+    max_decay_steps = tc.max_iters + 2
+    if it < tc.warmup_steps:
+        return max_lr * (it + 1) / tc.warmup_steps
+    if it > max_decay_steps:
+        return min_lr
+    ratio = min((it - tc.warmup_steps) / (max_decay_steps - tc.warmup_steps), 1.0)
+    return min_lr + 0.5 * (1 + math.cos(math.pi * ratio)) * (max_lr - min_lr)
+
+
+@torch.no_grad()
+def estimate_loss(model, tc: Trainconfig, train_loader, val_loader):
+    """Mean loss over ``eval_iters`` batches of each split (reference: single-gpu/train.py:280-293)."""
+    out = {}
+    model.eval()
+    model.VAL_RUN = True
+    for split, loader in (("train", train_loader), ("val", val_loader)):
+        losses = torch.zeros(tc.eval_iters, device=loader.device)
+        for k in range(tc.eval_iters):
+            X, Y = loader.next_batch()
+            _, loss, _ = model(X, Y)
+            losses[k] = loss.detach().float()
+        out[split] = losses.mean().item()
+    model.train()
+    model.VAL_RUN = False
+    return out
+
+
+def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
+    kw = dict(weight_decay=tc.weight_decay, lr=tc.learning_rate, dtype=tc.dtype, bucket_mb=tc.bucket_mb,
+              device=info.device)
+    if mode == "single":
+        from .parallel.engine import Engine
+        return Engine(model, **kw)
+    if mode == "ddp":
+        from .parallel.ddp import DDPEngine
+        return DDPEngine(model, **kw)
+    if mode in ("zero1", "zero2"):
+        from .parallel.zero import ZeroEngine
+        return ZeroEngine(model, stage=int(mode[-1]), **kw)
+    if mode == "fsdp":
+        from .parallel.fsdp import FSDPEngine
+        return FSDPEngine(model, **kw)
+    raise ValueError(f"unknown parallel mode {mode!r}")
+
+
+def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
+    info = comm.init_distributed() if mode != "single" else comm.DistInfo(
+        0, 0, 1, torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu"), "none")
+    master = info.is_master
+    device = info.device
+    torch.manual_seed(tc.seed + info.rank)
+    if device.type == "cuda":
+        torch.cuda.manual_seed(tc.seed + info.rank)
+
+    def say(*a):
+        if master:
+            print(*a, flush=True)
+
+    if mode != "single":
+        say(f"DDP_WORLD_SIZE = {info.world_size}" if mode != "fsdp" else f"Num GPUs = {info.world_size}")
+
+    # ---- data ------------------------------------------------------------------------------
+    data_dir = resolve_data_dir(tc.dataset, tc.data_dir)
+    if tc.synthetic_tokens > 0 or tc.dataset == "synthetic":
+        n = tc.synthetic_tokens or max(4 * tc.total_batch_size, 1 << 20)
+        data_dir = ensure_synthetic(data_dir, n, mc.vocab_size, info.rank, tc.seed)
+    say(f"Using Dataset {os.path.basename(data_dir)}")
+    B, T = tc.batch_size, mc.block_size
+    train_loader = DataLoader(B, T, os.path.join(data_dir, "train.bin"), device, info.rank, info.world_size, tc.seed)
+    val_loader = DataLoader(B, T, os.path.join(data_dir, "val.bin"), device, info.rank, info.world_size, tc.seed + 7)
+
+    # ---- gradient accumulation -------------------------------------------------------------
+    denom = B * T * info.world_size
+    assert tc.total_batch_size % denom == 0, "make sure total_batch_size is divisible by B * T * world_size"
+    grad_accum_steps = tc.total_batch_size // denom
+
+    # ---- model + engine --------------------------------------------------------------------
+    model = LLM(mc)
+    total, active = model.get_num_params()
+    say(f"total parameters = {total:,}, acitive parameters = {active:,}")
+    flops_tok = model_flops_per_token(model, T)
+    engine = build_engine(mode, model, tc, info)
+    say("Using Fused AdamW")
+    if mc.act_recomp:
+        say("Using Activation Recomputation")
+    optimizer = engine.configure_optimizers(weight_decay=tc.weight_decay, learning_rate=tc.learning_rate, device=device)
+
+    start_iter = 0
+    if tc.resume:
+        start_iter = load_resume(tc.resume, engine, (train_loader, val_loader), info.rank) + 1
+        say(f"resumed from {tc.resume} at iteration {start_iter}")
+
+    sink = JsonlSink(tc.metrics_jsonl if master else "")
+    timer = PhaseTimer(tc.profile)
+    train_loss_stats, valrun_val, valrun_train = [], [], []
+    x, y = train_loader.next_batch()
+    last_loss = float("nan")
+    tokens_per_s = 0.0
+    for it in range(start_iter, tc.max_iters + 1):
+        t0 = perf_counter()
+        lr = get_lr(it, tc)
+        for pg in optimizer.param_groups:
+            pg["lr"] = lr
+        optimizer.zero_grad(set_to_none=True)
+
+        if tc.eval and (it % tc.eval_interval == 0 or it == tc.max_iters) and it != 0:
+            a = perf_counter()
+            losses = estimate_loss(engine, tc, train_loader, val_loader)
+            valrun_val.append(losses["val"])
+            valrun_train.append(losses["train"])
+            b = perf_counter()
+            say(f"--------val run-------- train loss {losses['train']:.4f} | val loss {losses['val']:.4f} | "
+                f"dt {1000 * (b - a):.4f}ms")
+            t0 = b
+
+        for micro_step in range(grad_accum_steps):
+            engine.require_backward_grad_sync = (micro_step == grad_accum_steps - 1)
+            with timer.phase("forward"):
+                _, loss, _ = engine(x, y)
+                loss = loss / grad_accum_steps
+            x, y = train_loader.next_batch()   # host work overlaps the queued GPU work
+            with timer.phase("backward"):
+                loss.backward()
+
+        with timer.phase("optimizer"):
+            if tc.grad_clip != 0.0:
+                engine.clip_grad_norm_(tc.grad_clip)
+            optimizer.step()
+
+        read_loss = (it % max(tc.sync_loss_every, 1) == 0) or it == tc.max_iters
+        if read_loss:
+            last_loss = loss.item() * grad_accum_steps   # the only host<-device sync of the step
+            train_loss_stats.append(last_loss)
+        mem = 0
+        if device.type == "cuda":
+            if read_loss:
+                torch.cuda.synchronize()
+            mem = torch.cuda.memory_reserved()
+        dt = perf_counter() - t0
+        tokens_per_s = tc.total_batch_size / dt
+        util = mfu(tokens_per_s, flops_tok, info.world_size)
+        if it % max(tc.log_interval, 1) == 0:
+            say(f"step: {it} | train loss:{last_loss:.4f} | dt: {1000 * dt:.2f}ms | "
+                f"grad_accum_steps: {grad_accum_steps} | GPU RAM: {mem / 1024 ** 3:.2f}GB | "
+                f"tok/s: {tokens_per_s:,.0f} | MFU: {100 * util:.2f}%")
+        sink.write(step=it, loss=last_loss, dt_ms=1000 * dt, tokens_per_s=tokens_per_s, mfu=util, lr=lr,
+                   mem_gb=mem / 1024 ** 3, peak_flops=PEAK_BF16_DENSE_FLOPS)
+        if tc.save_interval and it > 0 and it % tc.save_interval == 0:
+            save_resume(tc.file_name + "_resume", engine, it, (train_loader, val_loader), info.rank, info.world_size)
+
+    if tc.profile and master:
+        print(timer.report(), flush=True)
+    result = {"final_loss": last_loss, "tokens_per_s": tokens_per_s, "losses": train_loss_stats,
+              "grad_accum_steps": grad_accum_steps, "total_params": total, "active_params": active}
+    if tc.save_model:
+        loss_stats = {"train": train_loss_stats, "valrun_val": valrun_val, "valrun_train": valrun_train}
+        path = save_reference_checkpoint(engine, mc, tc, tc.file_name, loss_stats, total, active, info.rank)
+        if master:
+            say("Model and config saved to {}.pt".format(tc.file_name + "_ckpt"))
+            say("Stats and config saved to {}.pt".format(tc.file_name + "_stats"))
+            result["checkpoint"] = path
+    sink.close()
+    if mode != "single":
+        comm.barrier()
+        comm.shutdown()
+    return result

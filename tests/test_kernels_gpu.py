@@ -1,0 +1,279 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from distributed_pytorch_amd import _ext
+    return _ext.require()
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,C", [(1024, 768), (37, 256), (4096, 1024), (513, 2048), (64, 4096)])
+def test_layernorm_fwd_bwd(dtype, rows, C):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(rows, C, device=DEV, dtype=dtype) * 2 + 0.5
+    w = (torch.randn(C, device=DEV) * 0.5 + 1).to(dtype)
+    b = (torch.randn(C, device=DEV) * 0.1).to(dtype)
+    dy = torch.randn(rows, C, device=DEV, dtype=dtype)
+    xr, wr, br = [t.float().detach().requires_grad_() for t in (x, w, b)]
+    yr = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    yr.backward(dy.float())
+    xs, ws, bs = [t.detach().clone().requires_grad_() for t in (x, w, b)]
+    y = ops.layer_norm(xs, ws, bs, 1e-5)
+    y.backward(dy)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5
+    assert rel_err(y, yr) < tol
+    assert rel_err(xs.grad, xr.grad) < tol
+    assert rel_err(ws.grad, wr.grad) < tol
+    assert rel_err(bs.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_add_layernorm(dtype):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(1)
+    rows, C = 777, 768
+    x = torch.randn(rows, C, device=DEV, dtype=dtype)
+    r = torch.randn(rows, C, device=DEV, dtype=dtype)
+    w = (torch.rand(C, device=DEV) + 0.5).to(dtype)
+    b = torch.randn(C, device=DEV).to(dtype)
+    g1 = torch.randn(rows, C, device=DEV, dtype=dtype)
+    g2 = torch.randn(rows, C, device=DEV, dtype=dtype)
+    xr, rr, wr, br = [t.float().detach().requires_grad_() for t in (x, r, w, b)]
+    sr = (xr + rr).to(dtype).float() if dtype == torch.bfloat16 else xr + rr
+    sr = xr + rr
+    yr = F.layer_norm(sr, (C,), wr, br, 1e-5)
+    (sr * g1.float() + yr * g2.float()).sum().backward()
+    xs, rs, ws, bs = [t.detach().clone().requires_grad_() for t in (x, r, w, b)]
+    s, y = ops.add_layer_norm(xs, rs, ws, bs, 1e-5)
+    (s.float() * g1.float() + y.float() * g2.float()).sum().backward()
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 2e-5
+    assert rel_err(s, sr) < tol and rel_err(y, yr) < tol
+    assert rel_err(xs.grad, xr.grad) < tol and rel_err(rs.grad, rr.grad) < tol
+    assert rel_err(ws.grad, wr.grad) < tol and rel_err(bs.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("gdtype", [torch.bfloat16, torch.float32])
+def test_fused_adamw_matches_torch(gdtype):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(2)
+    n, d = 8 * 1000, 8 * 600
+    p0 = torch.randn(n, device=DEV)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([{"params": [ref], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    # two segments with different decay: emulate with two torch params
+    ref_a = p0[:d].clone().requires_grad_()
+    ref_b = p0[d:].clone().requires_grad_()
+    opt = torch.optim.AdamW([{"params": [ref_a], "weight_decay": 0.1}, {"params": [ref_b], "weight_decay": 0.0}],
+                            lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    master = p0.clone()
+    m = torch.zeros_like(master)
+    v = torch.zeros_like(master)
+    pout = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+    for step in range(1, 6):
+        g = (torch.randn(n, device=DEV) * 0.1).to(gdtype)
+        ref_a.grad = g[:d].float().clone()
+        ref_b.grad = g[d:].float().clone()
+        opt.step()
+        ops.adamw_step(master, m, v, g, pout, [(d, 0.1), (n, 0.0)], 1e-2, 0.9, 0.95, 1e-8, step)
+    want = torch.cat([ref_a.detach(), ref_b.detach()])
+    assert rel_err(master, want) < 1e-5
+    assert rel_err(pout, want) < 5e-3
+
+
+def test_adamw_clip_and_overflow_skip():
+    from distributed_pytorch_amd import ops
+    n = 4096
+    master = torch.ones(n, device=DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    g = torch.full((n,), 2.0, device=DEV)
+    norm2 = torch.zeros(1, device=DEV)
+    ops.sumsq(g, norm2)
+    assert abs(norm2.item() - 4.0 * n) < 1e-2 * n
+    # clip to norm 1: effective grad = g / ||g||
+    ops.adamw_step(master, m, v, g, None, [(n, 0.0)], 0.1, 0.9, 0.999, 1e-8, 1, norm2, 1.0, 1.0)
+    geff = 2.0 / math.sqrt(4.0 * n)
+    assert torch.allclose(m, torch.full_like(m, 0.1 * geff), rtol=1e-4)
+    before = master.clone()
+    bad = torch.tensor([float("inf")], device=DEV)
+    ops.adamw_step(master, m, v, g, None, [(n, 0.0)], 0.1, 0.9, 0.999, 1e-8, 2, bad, 1.0, 1.0)
+    assert torch.equal(master, before)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,V", [(64, 50304), (300, 4096), (17, 512)])
+def test_cross_entropy(dtype, rows, V):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(3)
+    logits = (torch.randn(rows, V, device=DEV) * 3).to(dtype)
+    tgt = torch.randint(0, V, (rows,), device=DEV)
+    tgt[::5] = -1
+    lr_ = logits.float().detach().requires_grad_()
+    want = F.cross_entropy(lr_, tgt, ignore_index=-1)
+    want.backward()
+    ls = logits.detach().clone().requires_grad_()
+    got = ops.cross_entropy(ls, tgt)
+    got.backward()
+    assert abs(got.item() - want.item()) < 2e-3 * max(1.0, abs(want.item()))
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(ls.grad, lr_.grad) < tol
+    assert torch.equal(ls.detach(), logits)  # input logits untouched
+
+
+def test_linear_cross_entropy_matches_unfused():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(4)
+    N, C, V = 3000, 256, 50304
+    x = (torch.randn(N, C, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_()
+    w = (torch.randn(V, C, device=DEV) * 0.05).to(torch.bfloat16).requires_grad_()
+    tgt = torch.randint(0, V, (N,), device=DEV)
+    tgt[:7] = -1
+    loss = ops.linear_cross_entropy(x, w, tgt, chunk_rows=1024)
+    (loss * 0.5).backward()
+    xr = x.detach().float().requires_grad_()
+    wr = w.detach().float().requires_grad_()
+    want = F.cross_entropy(xr @ wr.t(), tgt, ignore_index=-1)
+    (want * 0.5).backward()
+    assert abs(loss.item() - want.item()) < 5e-3 * want.item()
+    assert rel_err(x.grad, xr.grad) < 2e-2
+    assert rel_err(w.grad, wr.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_embedding_fwd_bwd(dtype):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(5)
+    V, C, B, T = 1000, 768, 4, 128
+    wte = torch.randn(V, C, device=DEV).to(dtype).requires_grad_()
+    wpe = torch.randn(256, C, device=DEV).to(dtype).requires_grad_()
+    idx = torch.randint(0, 50, (B, T), device=DEV)   # many repeats -> long runs in the sorted backward
+    out = ops.embedding(idx, wte, wpe, 3)
+    g = torch.randn_like(out)
+    out.backward(g)
+    wr = wte.detach().float().requires_grad_()
+    pr = wpe.detach().float().requires_grad_()
+    want = F.embedding(idx, wr) + pr[3:3 + T]
+    want.backward(g.float())
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(out, want) < tol
+    assert rel_err(wte.grad, wr.grad) < tol
+    assert rel_err(wpe.grad, pr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gelu_swiglu(dtype):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(6)
+    x = (torch.randn(333, 1024, device=DEV) * 2).to(dtype).requires_grad_()
+    g = torch.randn(333, 1024, device=DEV).to(dtype)
+    y = ops.gelu(x)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_()
+    yr = F.gelu(xr)
+    yr.backward(g.float())
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(y, yr) < tol and rel_err(x.grad, xr.grad) < tol
+    h = (torch.randn(200, 2 * 384, device=DEV)).to(dtype).requires_grad_()
+    g2 = torch.randn(200, 384, device=DEV).to(dtype)
+    z = ops.swiglu(h)
+    z.backward(g2)
+    hr = h.detach().float().requires_grad_()
+    a, b = hr.chunk(2, dim=-1)
+    zr = F.silu(a) * b
+    zr.backward(g2.float())
+    assert rel_err(z, zr) < tol and rel_err(h.grad, hr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rope_matches_complex_rotation(dtype):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(7)
+    B, T, H, hs, pos0 = 2, 50, 6, 64, 5
+    x = torch.randn(B, T, H, hs, device=DEV).to(dtype).requires_grad_()
+    cos_t, sin_t = ops.rope_tables(128, hs, device=DEV)
+    y = ops.apply_rope(x, cos_t, sin_t, pos0)
+    g = torch.randn_like(y)
+    y.backward(g)
+    # reference: complex multiplication as in the reference model
+    freqs = torch.polar(torch.ones_like(cos_t), torch.atan2(sin_t, cos_t))[pos0:pos0 + T]
+    xr = x.detach().float().requires_grad_()
+    xc = torch.view_as_complex(xr.reshape(B, T, H, hs // 2, 2))
+    yr = torch.view_as_real(xc * freqs.view(1, T, 1, hs // 2)).flatten(3)
+    yr.backward(g.float())
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(y, yr) < tol and rel_err(x.grad, xr.grad) < tol
+
+
+def _attn_ref(q, k, v, scale):
+    B, Tq, nh, hs = q.shape
+    Tk, nkv = k.shape[1], k.shape[2]
+    qh = q.float().transpose(1, 2)
+    kh = k.float().transpose(1, 2).repeat_interleave(nh // nkv, dim=1)
+    vh = v.float().transpose(1, 2).repeat_interleave(nh // nkv, dim=1)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    mask = torch.ones(Tq, Tk, dtype=torch.bool, device=q.device).tril(diagonal=Tk - Tq)
+    s = s.masked_fill(~mask, float("-inf"))
+    return (torch.softmax(s, dim=-1) @ vh).transpose(1, 2)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,nh,nkv,hs", [
+    (2, 256, 256, 4, 4, 64),
+    (1, 1024, 1024, 12, 12, 64),
+    (2, 200, 200, 8, 2, 64),      # GQA + ragged T
+    (2, 384, 384, 4, 1, 128),     # MQA, hs 128
+    (1, 130, 130, 2, 2, 128),
+    (2, 1, 77, 4, 2, 64),         # single-token decode against a cache
+    (1, 40, 300, 4, 4, 64),       # chunked prefill against a cache
+])
+def test_flash_attention_fwd_bwd(B, Tq, Tk, nh, nkv, hs):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(8)
+    q = torch.randn(B, Tq, nh, hs, device=DEV).to(torch.bfloat16).requires_grad_()
+    k = torch.randn(B, Tk, nkv, hs, device=DEV).to(torch.bfloat16).requires_grad_()
+    v = torch.randn(B, Tk, nkv, hs, device=DEV).to(torch.bfloat16).requires_grad_()
+    scale = 1.0 / math.sqrt(hs)
+    o = ops.causal_attention(q, k, v, scale)
+    g = torch.randn_like(o)
+    o.backward(g)
+    qr, kr, vr = [t.detach().float().requires_grad_() for t in (q, k, v)]
+    orf = _attn_ref(qr, kr, vr, scale)
+    orf.backward(g.float())
+    assert rel_err(o, orf) < 1e-2
+    assert rel_err(q.grad, qr.grad) < 2e-2
+    assert rel_err(k.grad, kr.grad) < 2e-2
+    assert rel_err(v.grad, vr.grad) < 2e-2
+
+
+def test_flash_attention_fused_qkv_and_spike():
+    """Fused-QKV entry point + a row whose max jumps late (exercises the online-softmax rescale)."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(9)
+    B, T, nh, nkv, hs = 2, 512, 6, 3, 64
+    qkv = torch.randn(B, T, (nh + 2 * nkv) * hs, device=DEV)
+    q, k, v = ops.split_qkv(qkv, nh, nkv)
+    k[0, 400, 0] = q[0, 450, 0] * 4.0     # a late, very large score for query 450 of head 0/1
+    qkv = qkv.to(torch.bfloat16).requires_grad_()
+    o = ops.causal_self_attention_qkv(qkv, nh, nkv)
+    g = torch.randn_like(o)
+    o.backward(g)
+    ref_in = qkv.detach().float().requires_grad_()
+    qr, kr, vr = ops.split_qkv(ref_in, nh, nkv)
+    orf = _attn_ref(qr, kr, vr, 1.0 / math.sqrt(hs))
+    orf.backward(g.float())
+    assert rel_err(o, orf) < 1e-2
+    assert rel_err(qkv.grad, ref_in.grad) < 2e-2
