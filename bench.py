@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GPT-2-124M bf16 training throughput (tokens/s, whole job) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One rank per GPU over RCCL. Every timed step is a full training step: data fetch (synthetic
+uint16 token file through the memmap loader, H2D copy), forward, backward with overlapped
+gradient collectives, global-norm clip, fused AdamW. Weak scaling: the per-GPU micro-batch is
+fixed. Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from distributed_pytorch_amd.config import PRESETS, LLMconfig, Trainconfig  # noqa: E402
+from distributed_pytorch_amd.data import DataLoader, ensure_synthetic  # noqa: E402
+from distributed_pytorch_amd.models.llm import LLM  # noqa: E402
+from distributed_pytorch_amd.parallel import comm  # noqa: E402
+from distributed_pytorch_amd.trainer import build_engine, get_lr  # noqa: E402
+from distributed_pytorch_amd.utils.metrics import PEAK_BF16_DENSE_FLOPS, mfu, model_flops_per_token  # noqa: E402
+
+# tokens/s of the reference's own single-GPU trainer loop (eager PyTorch, bf16 autocast, fused
+# AdamW, no torch.compile: there is no Triton on this image) for GPT-2-124M at micro-batch 16 on
+# one MI355X, measured with benchmarks/reference_baseline.py. None until measured.
+REFERENCE_TOKENS_PER_S_PER_GPU = None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", type=str, default="ddp", choices=["single", "ddp", "zero1", "zero2", "fsdp"])
+    ap.add_argument("--model", type=str, default="gpt2-124m", choices=sorted(PRESETS))
+    ap.add_argument("--batch", type=int, default=32, help="micro-batch (sequences) per GPU")
+    ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--accum", type=int, default=1)
+    ap.add_argument("--bucket_mb", type=float, default=48.0)
+    ap.add_argument("--act_recomp", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py measures on the GPU"
+    mode = args.mode if world > 1 else ("single" if args.mode == "ddp" else args.mode)
+    info = comm.init_distributed() if world > 1 else comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "none")
+    torch.cuda.set_device(info.device)
+    torch.manual_seed(1729 + info.rank)
+
+    mc = LLMconfig(**{**LLMconfig().to_dict(), **PRESETS[args.model]})
+    mc.block_size = args.seq
+    mc.act_recomp = args.act_recomp
+    mc.finalize()
+    B, T = args.batch, args.seq
+    global_batch = B * world * args.accum
+    tc = Trainconfig(dataset="synthetic", total_batch_size=global_batch * T, batch_size=B,
+                     max_iters=args.steps + args.warmup, learning_rate=3e-4, warmup_steps=10, grad_clip=1.0,
+                     bucket_mb=args.bucket_mb, dtype="bf16")
+
+    data_dir = ensure_synthetic(os.path.join("/tmp", "dpa_bench_data"), 1 << 24, mc.vocab_size, info.rank)
+    loader = DataLoader(B, T, os.path.join(data_dir, "train.bin"), info.device, info.rank, world, 1729)
+
+    model = LLM(mc)
+    total, active = model.get_num_params()
+    flops_tok = model_flops_per_token(model, T)
+    if world > 1 or mode != "single":
+        engine = build_engine(mode, model, tc, info)
+    else:
+        engine = build_engine("single", model, tc, info)
+    optimizer = engine.configure_optimizers(learning_rate=tc.learning_rate)
+
+    x, y = loader.next_batch()
+
+    def step(it: int):
+        nonlocal x, y
+        lr = get_lr(it, tc)
+        for pg in optimizer.param_groups:
+            pg["lr"] = lr
+        optimizer.zero_grad(set_to_none=True)
+        loss = None
+        for micro in range(args.accum):
+            engine.require_backward_grad_sync = (micro == args.accum - 1)
+            _, loss, _ = engine(x, y)
+            loss = loss / args.accum
+            x, y = loader.next_batch()
+            loss.backward()
+        engine.clip_grad_norm_(tc.grad_clip)
+        optimizer.step()
+        return loss
+
+    for it in range(args.warmup):
+        loss = step(it)
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        loss = step(it)
+    torch.cuda.synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=info.device)
+    if world > 1:
+        comm.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = el.item()
+    final_loss = loss.item() * args.accum
+
+    if info.rank == 0:
+        tokens = global_batch * T * args.steps
+        tps = tokens / elapsed
+        ref = REFERENCE_TOKENS_PER_S_PER_GPU
+        out = {
+            "metric": "tokens_per_sec", "value": tps, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": (tps / (ref * world)) if ref else None, "dtype": "bf16",
+            "data": "synthetic", "mfu": mfu(tps, flops_tok, world), "peak_flops_per_gpu": PEAK_BF16_DENSE_FLOPS,
+            "flops_per_token": flops_tok, "final_loss": final_loss,
+            "mem_gb": torch.cuda.max_memory_allocated() / 1024 ** 3,
+            "config": {"model": args.model, "params": total, "global_batch": global_batch, "micro_batch": B,
+                       "seq_len": T, "grad_accum": args.accum,
+                       "parallelism": f"{mode}{world}" if world > 1 else "single", "optimizer": "fused AdamW",
+                       "grad_clip": tc.grad_clip},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        comm.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -221,8 +221,11 @@ void embed_bwd(const Tensor& dout, const Tensor& ids_sorted, const Tensor& perm,
   TORCH_CHECK(dout.numel() == N * C && dout.scalar_type() == dwte.scalar_type(), "embed_bwd: dout mismatch");
   for (const Tensor* t : {&ids_sorted, &perm})
     TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kLong && t->is_contiguous() && t->numel() == N);
+  if (N == 0) return;
+  Tensor scratch = at::empty({2 * (int64_t)dpa::embed_bwd_chunks(N) * C}, dwte.options().dtype(at::kFloat));
   dpa::embed_bwd(dout.data_ptr(), (const long long*)ids_sorted.data_ptr<int64_t>(),
-                 (const long long*)perm.data_ptr<int64_t>(), dwte.data_ptr(), N, (int)C, is_bf16(dwte), cur_stream());
+                 (const long long*)perm.data_ptr<int64_t>(), dwte.data_ptr(), scratch.data_ptr<float>(), N, (int)C,
+                 is_bf16(dwte), cur_stream());
 }
 
 void pos_bwd(const Tensor& dout, Tensor dpos, int64_t pos0) {

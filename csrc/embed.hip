@@ -2,10 +2,11 @@
 //
 // Forward: out[n, :] = wte[idx[n], :] + pos[(pos0 + n % T), :]   (one fused gather + add)
 // Backward (token table): deterministic and atomic-free. The caller sorts the token ids once
-// (ids_sorted, perm); every run of equal ids is summed in fp32 by the workgroup that sits on
-// the run's first element and added to that row of the (tied lm_head / embedding) weight
-// gradient. No two workgroups touch the same row, so bf16 gradients are summed exactly once
-// from an fp32 accumulator.
+// (ids_sorted, perm); runs of equal ids are summed in fp32 in two passes (fixed-size chunks,
+// then a fold of the chunk-crossing runs) and added to that row of the (tied lm_head /
+// embedding) weight gradient. No two workgroups touch the same row, so bf16 gradients are
+// summed exactly once from an fp32 accumulator, and a very frequent token costs no more than
+// a rare one.
 // Backward (learned position table): dpos[t, :] += sum_b dout[b, t, :].
 //
 // Replaces `nn.Embedding` forward/backward (reference: single-gpu/model.py:541-543,652-666).
@@ -36,21 +37,86 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
   }
 }
 
+// Token-table backward, pass 1. The sorted positions are cut into chunks of kEmbChunk; one
+// workgroup sums the runs of equal ids inside its chunk in fp32. A run that lies completely
+// inside the chunk is added to its gradient row right away (no other workgroup touches that
+// row). A run that crosses the chunk's left / right edge is parked as the chunk's fp32
+// `head` / `tail` partial row for pass 2.
+constexpr int kEmbChunk = 32;
+
 template <typename T>
-__global__ __launch_bounds__(128) void embed_bwd_kernel(const T* __restrict__ dout, const long long* __restrict__ ids_sorted,
-                                                        const long long* __restrict__ perm, T* __restrict__ dwte,
-                                                        long long N, int C) {
-  const long long i = blockIdx.x;
-  const long long tok = ids_sorted[i];
-  if (i > 0 && ids_sorted[i - 1] == tok) return;  // not the head of a run
+__global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const T* __restrict__ dout,
+                                                              const long long* __restrict__ ids,
+                                                              const long long* __restrict__ perm,
+                                                              T* __restrict__ dwte, float* __restrict__ head,
+                                                              float* __restrict__ tail, long long N, int C) {
+  const long long s = (long long)blockIdx.x * kEmbChunk;
+  const long long e = (s + kEmbChunk < N) ? s + kEmbChunk : N;
+  const bool cont_prev = s > 0 && ids[s - 1] == ids[s];
+  const bool cont_next = e < N && ids[e] == ids[e - 1];
   const int nvec = C >> 3;
   for (int cv = threadIdx.x; cv < nvec; cv += blockDim.x) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long j = i; j < N && ids_sorted[j] == tok; ++j) {
-      float d[8];
-      load8(dout + (size_t)perm[j] * C + cv * 8, d);
+    long long run_start = s, tok = ids[s];
+    for (long long j = s; j <= e; ++j) {
+      const long long t = (j < e) ? ids[j] : -1;
+      if (t != tok) {  // flush the run [run_start, j)
+        if (run_start == s && cont_prev) {
+          store8(head + (size_t)blockIdx.x * C + cv * 8, acc);
+        } else if (j == e && cont_next) {
+          store8(tail + (size_t)blockIdx.x * C + cv * 8, acc);
+        } else {
+          float g[8];
+          load8(dwte + (size_t)tok * C + cv * 8, g);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] += d[k];
+          for (int k = 0; k < 8; ++k) g[k] += acc[k];
+          store8(dwte + (size_t)tok * C + cv * 8, g);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        tok = t;
+        run_start = j;
+      }
+      if (j < e) {
+        float d[8];
+        load8(dout + (size_t)perm[j] * C + cv * 8, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += d[k];
+      }
+    }
+  }
+}
+
+// Pass 2: the chunk in which a crossing run STARTS folds that run's tail and the head rows of
+// the following chunks (found with one binary search for the run's end) and adds the sum to
+// the gradient row. Every crossing run has exactly one starting chunk, so rows are written
+// once, without atomics, in a fixed order (bitwise reproducible).
+template <typename T>
+__global__ __launch_bounds__(128) void embed_bwd_fix_kernel(const long long* __restrict__ ids, T* __restrict__ dwte,
+                                                            const float* __restrict__ head,
+                                                            const float* __restrict__ tail, long long N, int C) {
+  const long long s = (long long)blockIdx.x * kEmbChunk;
+  const long long e = (s + kEmbChunk < N) ? s + kEmbChunk : N;
+  const long long tok = ids[e - 1];
+  const bool cont_next = e < N && ids[e] == tok;
+  if (!cont_next) return;
+  const bool whole = ids[s] == tok;  // the chunk is a single run
+  if (whole && s > 0 && ids[s - 1] == tok) return;  // the run started in an earlier chunk
+  long long lo = e, hi = N;  // first position > e-1 whose id differs from tok
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (ids[mid] == tok) lo = mid + 1; else hi = mid;
+  }
+  const long long last_chunk = (lo - 1) / kEmbChunk;
+  const int nvec = C >> 3;
+  for (int cv = threadIdx.x; cv < nvec; cv += blockDim.x) {
+    float acc[8];
+    load8(tail + (size_t)blockIdx.x * C + cv * 8, acc);
+    for (long long j = blockIdx.x + 1; j <= last_chunk; ++j) {
+      float h[8];
+      load8(head + (size_t)j * C + cv * 8, h);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += h[k];
     }
     float g[8];
     load8(dwte + (size_t)tok * C + cv * 8, g);
@@ -100,16 +166,24 @@ void embed_fwd(const long long* idx, const void* wte, const void* pos, void* out
                        (float*)out, N, T_len, pos0, C);
 }
 
-void embed_bwd(const void* dout, const long long* ids_sorted, const long long* perm, void* dwte, long long N, int C,
-               bool is_bf16, hipStream_t st) {
+int embed_bwd_chunks(long long N) { return (int)((N + kEmbChunk - 1) / kEmbChunk); }
+
+void embed_bwd(const void* dout, const long long* ids_sorted, const long long* perm, void* dwte, float* scratch,
+               long long N, int C, bool is_bf16, hipStream_t st) {
   if (N == 0) return;
-  const dim3 grid((unsigned)N), block(128);
-  if (is_bf16)
-    hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids_sorted, perm,
-                       (bf16_t*)dwte, N, C);
-  else
-    hipLaunchKernelGGL((embed_bwd_kernel<float>), grid, block, 0, st, (const float*)dout, ids_sorted, perm,
-                       (float*)dwte, N, C);
+  const int nch = embed_bwd_chunks(N);
+  float* head = scratch;
+  float* tail = scratch + (size_t)nch * C;
+  const dim3 grid(nch), block(128);
+  if (is_bf16) {
+    hipLaunchKernelGGL((embed_bwd_chunk_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids_sorted, perm,
+                       (bf16_t*)dwte, head, tail, N, C);
+    hipLaunchKernelGGL((embed_bwd_fix_kernel<bf16_t>), grid, block, 0, st, ids_sorted, (bf16_t*)dwte, head, tail, N, C);
+  } else {
+    hipLaunchKernelGGL((embed_bwd_chunk_kernel<float>), grid, block, 0, st, (const float*)dout, ids_sorted, perm,
+                       (float*)dwte, head, tail, N, C);
+    hipLaunchKernelGGL((embed_bwd_fix_kernel<float>), grid, block, 0, st, ids_sorted, (float*)dwte, head, tail, N, C);
+  }
 }
 
 void pos_bwd(const void* dout, void* dpos, int B, int T_len, int pos0, int C, bool is_bf16, hipStream_t st) {

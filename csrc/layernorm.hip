@@ -162,28 +162,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// Fold `nparts` partial rows into the parameter gradients. With `accumulate` the result is
-// added to what dw/db already hold (gradient accumulation into a flat gradient buffer).
+// Fold `nparts` partial rows into the parameter gradients. One 1024-thread block owns 64
+// columns; its 16 wave-rows each walk every 16th partial row with independent (unrolled)
+// loads, so the fold is a handful of memory round trips instead of a serial chain. With
+// `accumulate` the result is added to what dw/db already hold.
 template <typename T>
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part_dw, const float* __restrict__ part_db,
-                                     T* __restrict__ dw, T* __restrict__ db, int nparts, int C, int accumulate) {
-  __shared__ float red[2][4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int seg = threadIdx.x >> 6;  // 4 segments of the partial rows
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ part_dw,
+                                                             const float* __restrict__ part_db, T* __restrict__ dw,
+                                                             T* __restrict__ db, int nparts, int C, int accumulate) {
+  __shared__ float red[2][16][64];
+  const int l = threadIdx.x & 63;
+  const int col = blockIdx.x * 64 + l;
+  const int seg = threadIdx.x >> 6;
   float sw = 0.f, sb = 0.f;
   if (col < C) {
-    for (int p = seg; p < nparts; p += 4) {
+    int p = seg;
+    for (; p + 48 < nparts; p += 64) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = part_dw[(size_t)(p + 16 * u) * C + col];
+        b[u] = part_db[(size_t)(p + 16 * u) * C + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sw += a[u];
+        sb += b[u];
+      }
+    }
+    for (; p < nparts; p += 16) {
       sw += part_dw[(size_t)p * C + col];
       sb += part_db[(size_t)p * C + col];
     }
   }
-  red[0][seg][threadIdx.x & 63] = sw;
-  red[1][seg][threadIdx.x & 63] = sb;
+  red[0][seg][l] = sw;
+  red[1][seg][l] = sb;
   __syncthreads();
   if (seg == 0 && col < C) {
-    const int l = threadIdx.x;
-    float tw = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-    float tb = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    float tw = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      tw += red[0][k][l];
+      tb += red[1][k][l];
+    }
     if (accumulate) {
       tw += Cvt<T>::ld(dw + col);
       tb += Cvt<T>::ld(db + col);
@@ -232,7 +253,7 @@ static void ln_bwd_launch(const T* dy, const T* x, const T* w, const float* mean
     DPA_CASE(1) DPA_CASE(2) DPA_CASE(4) DPA_CASE(8) DPA_CASE(16)
 #undef DPA_CASE
   }
-  hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3((C + 63) / 64), dim3(256), 0, st, pw, pb, dw, db, nparts,
+  hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3((C + 63) / 64), dim3(1024), 0, st, pw, pb, dw, db, nparts,
                      C, accumulate);
 }
 
@@ -240,7 +261,7 @@ int layernorm_max_cols() { return 16 * 64 * 8; }  // 8192; LDS in the backward: 
 
 int layernorm_bwd_parts(int rows) {
   int n = (rows + 3) / 4;
-  return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+  return n < 1 ? 1 : (n > 512 ? 512 : n);  // 2 workgroups (8 waves) per CU keep HBM busy
 }
 
 void layernorm_fwd(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out,

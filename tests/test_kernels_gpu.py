@@ -175,6 +175,23 @@ def test_embedding_fwd_bwd(dtype):
     assert rel_err(wpe.grad, pr.grad) < tol
 
 
+@pytest.mark.parametrize("N,hot", [(1000, 1.0), (4099, 0.6), (33, 0.0), (64, 1.0)])
+def test_embedding_bwd_skewed_runs(N, hot):
+    """Long runs of one token crossing many chunks of the sorted backward, ragged N."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(55)
+    V, C = 300, 256
+    idx = torch.randint(0, V, (1, N), device=DEV)
+    idx[0, torch.rand(N, device=DEV) < hot] = 7
+    wte = torch.randn(V, C, device=DEV).requires_grad_()
+    out = ops.embedding(idx, wte, None, 0)
+    g = torch.randn_like(out)
+    out.backward(g)
+    wr = wte.detach().clone().requires_grad_()
+    F.embedding(idx, wr).backward(g)
+    assert rel_err(wte.grad, wr.grad) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gelu_swiglu(dtype):
     from distributed_pytorch_amd import ops
