@@ -40,7 +40,8 @@ def save_reference_checkpoint(engine_or_model, model_config, train_config, file_
     return file_name + "_ckpt.pt"
 
 
-def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None):
+def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None,
+                loader_states=None):
     """Per-rank resume file ``<path>.rank<r>`` (optimizer shards are rank-local)."""
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     payload = {
@@ -50,7 +51,7 @@ def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: in
         "buffers": {k: v.detach().cpu() for k, v in engine.module.named_buffers() if v is not None},
         "torch_rng": torch.get_rng_state(),
         "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
-        "loaders": [l.state_dict() for l in loaders],
+        "loaders": loader_states if loader_states is not None else [l.state_dict() for l in loaders],
         "extra": extra or {},
     }
     tmp = f"{path}.rank{rank}.tmp"

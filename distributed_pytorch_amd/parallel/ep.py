@@ -1,0 +1,230 @@
+"""Expert parallelism for the MoE layers: routed experts are sharded over the ranks of a
+process group and tokens travel to their experts and back with two all-to-alls per layer.
+
+Layout: with ``E`` ranks and ``n_routed`` routed experts, rank ``r`` owns the contiguous block
+of ``n_routed / E`` experts starting at ``r * n_routed / E`` (8 experts on 8 GPUs -> one
+expert per GPU, top-2 routing -> every token row is sent to at most two peers). On a fully
+connected xGMI mesh every pair of GPUs has its own link, so an all-to-all with per-peer splits
+uses all 7 links of every GPU at once.
+
+Per MoE forward:
+  1. route locally (same math as the single-device layer);
+  2. sort the (token, slot) pairs by expert id == by destination rank;
+  3. exchange the per-expert row counts (tiny int all-to-all), then the rows themselves (bf16);
+  4. each rank regroups what it received by local expert, runs its experts on contiguous
+     slices, and sends the outputs back along the reverse all-to-all;
+  5. scale by the gate and scatter-add into the token order.
+The all-to-all is an autograd function whose backward is the all-to-all with the split sizes
+swapped, so dispatch and combine are differentiable end to end.
+
+Gradients: an expert receives every token routed to it from all ranks, so its gradient is
+already the global sum — expert parameters are NOT all-reduced; dense parameters are reduced
+as in ``DDPEngine``. Both are scaled by 1/W in the optimizer (the loss is a per-rank mean).
+Non-local experts are dropped from the module's trainable set (their storage is freed);
+``state_dict()`` gathers every expert back so that checkpoints keep the reference key schema.
+
+The reference has the MoE layer but no expert parallelism (listed as a goal only,
+reference: README.md:7; single-gpu/model.py:490-502 loops over all experts locally).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+from . import comm
+from .ddp import DDPEngine
+from .flat import FlatAdamW, FlatGroup, plan_groups, unique_named_parameters
+
+
+class _AllToAllRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, in_splits, out_splits, group):
+        ctx.splits = (in_splits, out_splits)
+        ctx.group = group
+        out = x.new_empty((sum(out_splits),) + tuple(x.shape[1:]))
+        comm.all_to_all(out, x.contiguous(), out_splits, in_splits, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        in_splits, out_splits = ctx.splits
+        gx = g.new_empty((sum(in_splits),) + tuple(g.shape[1:]))
+        comm.all_to_all(gx, g.contiguous(), in_splits, out_splits, group=ctx.group)
+        return gx, None, None, None
+
+
+def all_to_all_rows(x, in_splits, out_splits, group=None):
+    return _AllToAllRows.apply(x, list(in_splits), list(out_splits), group)
+
+
+class ExpertParallelDispatcher:
+    """Callable installed as ``MoE.dispatcher``."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = comm.world_size(group)
+        self.rank = comm.get_rank(group)
+
+    def local_expert_range(self, n_routed: int):
+        assert n_routed % self.world == 0, "n_routed must be divisible by the expert-parallel world size"
+        per = n_routed // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    def __call__(self, moe, x_flat, topk_indices, topk_gates):
+        W, per = self.world, moe.n_routed // self.world
+        N, k = topk_indices.shape
+        flat_e = topk_indices.reshape(-1)
+        order = torch.argsort(flat_e, stable=True)
+        tok = torch.div(order, k, rounding_mode="floor")
+        counts = torch.bincount(flat_e, minlength=moe.n_routed)            # rows per expert (global ids)
+        recv_counts = torch.empty_like(counts)
+        comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
+        counts_h = counts.view(W, per).sum(1).tolist()                      # rows sent to each rank
+        recv_mat = recv_counts.view(W, per)
+        recv_h = recv_mat.sum(1).tolist()                                   # rows received from each rank
+        xs = x_flat[tok]
+        recv = all_to_all_rows(xs, counts_h, recv_h, self.group)
+        # regroup the received rows (ordered by source rank, then expert) by local expert
+        R = recv.shape[0]
+        seg_expert = torch.arange(per, device=recv.device).repeat(W)        # expert id of each (src, expert) segment
+        row_expert = torch.repeat_interleave(seg_expert, recv_mat.reshape(-1), output_size=R)
+        perm = torch.argsort(row_expert, stable=True)
+        per_expert = recv_mat.sum(0).tolist()
+        grouped = recv[perm]
+        outs, start = [], 0
+        lo = self.rank * per
+        for j, c in enumerate(per_expert):
+            if c:
+                outs.append(moe.experts[moe.n_shared + lo + j](grouped[start:start + c]))
+            start += c
+        if outs:
+            y_grouped = torch.cat(outs, dim=0)
+        else:
+            y_grouped = grouped.new_zeros((0, x_flat.shape[1]))
+            # keep the local experts in the autograd graph so their (zero) gradients exist
+            y_grouped = y_grouped + 0.0 * sum(p.sum() for j in range(per)
+                                              for p in moe.experts[moe.n_shared + lo + j].parameters())
+        y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
+        y_back = all_to_all_rows(y_recv, recv_h, counts_h, self.group)
+        gs = topk_gates.reshape(-1)[order].unsqueeze(1)
+        return torch.zeros_like(x_flat).index_add_(0, tok, (y_back * gs).to(x_flat.dtype))
+
+
+def _expert_index(name: str):
+    """('transformer.h.3.moe.experts.5.expert.c_fc.weight') -> 5, or None."""
+    parts = name.split(".")
+    if "experts" in parts:
+        i = parts.index("experts")
+        if i > 0 and parts[i - 1] == "moe":
+            return int(parts[i + 1])
+    return None
+
+
+class EPEngine(DDPEngine):
+    """Data parallel for the dense parameters + expert parallel for the routed experts, both
+    over the same process group."""
+
+    name = "ep"
+
+    def _build_storage(self):
+        self.dispatcher = ExpertParallelDispatcher(self.group)
+        cfg = self.module.config
+        assert cfg.moe, "EPEngine needs an MoE model"
+        n_routed = cfg.n_exp - cfg.n_shared
+        lo, hi = self.dispatcher.local_expert_range(n_routed)
+        self._local_routed = (lo, hi)
+        local_named, self._dropped = [], []
+        for blk in self.module.transformer.h:
+            blk.moe.dispatcher = self.dispatcher
+        for n, p in unique_named_parameters(self.module):
+            ei = _expert_index(n)
+            if ei is not None and ei >= cfg.n_shared:
+                if lo <= ei - cfg.n_shared < hi:
+                    local_named.append((n, p))
+                else:
+                    p.requires_grad_(False)
+                    p.data = torch.empty(0, dtype=p.dtype, device=p.device)   # not owned here: free it
+                    self._dropped.append(n)
+        local_ids = {id(p) for _, p in local_named}
+        # dense parameters: bucketed + all-reduced (DDP); local experts: one group, never reduced
+        for _, p in local_named:
+            p.requires_grad_(False)
+        super()._build_storage()
+        for _, p in local_named:
+            p.requires_grad_(True)
+        self._n_dense_groups = len(self.groups)
+        if local_named:
+            g = FlatGroup(local_named, self.param_dtype, self.device, 8, self.weight_decay, "experts")
+            self.groups.append(g)
+            self.optims.append(FlatAdamW(g, 0, g.numel, betas=self.betas, eps=self.eps))
+            g.drop_init()
+            self._pending.append(0)
+            self._launched.append(True)
+
+    def _pre_forward(self):
+        super()._pre_forward()
+        for gi in range(self._n_dense_groups, len(self.groups)):
+            self._launched[gi] = True      # expert gradients are complete locally: nothing to reduce
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad()
+        for gi in range(self._n_dense_groups, len(self.groups)):
+            self._launched[gi] = True
+
+    def _compute_norm(self):
+        """||g||^2 = dense part (replicated, counted once) + sum over ranks of the expert parts."""
+        from .. import ops
+        dense = torch.zeros_like(self._norm2)
+        first = True
+        for g in self.groups[:self._n_dense_groups]:
+            ops.sumsq(g.grad, dense, accumulate=not first)
+            first = False
+        expert = torch.zeros_like(self._norm2)
+        first = True
+        for g in self.groups[self._n_dense_groups:]:
+            ops.sumsq(g.grad, expert, accumulate=not first)
+            first = False
+        comm.all_reduce(expert, group=self.group)
+        self._norm2.copy_(dense + expert)
+        self._have_norm = True
+
+    def state_dict(self, *args, **kwargs):
+        """Reference-schema state dict with every expert gathered from its owner (collective)."""
+        sd = OrderedDict()
+        by_name = {}
+        for gi, g in enumerate(self.groups):
+            full = self._full_master(gi)
+            for s in g.slots:
+                by_name[s.name] = full[s.offset:s.offset + s.numel].view(s.shape).detach().clone()
+        cfg = self.module.config
+        per = (cfg.n_exp - cfg.n_shared) // self.world
+        names = [k for k, _ in self.module.named_parameters(remove_duplicate=False)]
+        tied = {k: n2 for k, p in self.module.named_parameters(remove_duplicate=False)
+                for n2, p2 in by_name.items() if False}
+        params = dict(self.module.named_parameters(remove_duplicate=False))
+        first_name = {}
+        for k, p in params.items():
+            first_name.setdefault(id(p), k)
+        for k in names:
+            ei = _expert_index(k)
+            if ei is not None and ei >= cfg.n_shared:
+                owner = (ei - cfg.n_shared) // per
+                shape = self._expert_shape(k)
+                t = by_name[k].to(self.device) if owner == self.rank else torch.empty(shape, device=self.device)
+                comm.broadcast(t, src=owner, group=self.group)
+                sd[k] = t
+            else:
+                sd[k] = by_name[first_name[id(params[k])]]
+        for k, b in self.module.state_dict().items():
+            if k not in sd and k not in params:
+                sd[k] = b.detach().clone()
+        order = [k for k in self.module.state_dict().keys() if k in sd]
+        return OrderedDict((k, sd[k]) for k in order)
+
+    def _expert_shape(self, name: str):
+        cfg = self.module.config
+        if name.endswith("c_fc.weight"):
+            return ((2 if cfg.non_linearity.lower() == "swiglu" else 1) * cfg.up_dim, cfg.n_embd)
+        return (cfg.n_embd, cfg.up_dim)

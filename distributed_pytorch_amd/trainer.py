@@ -155,6 +155,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
             with timer.phase("forward"):
                 _, loss, _ = engine(x, y)
                 loss = loss / grad_accum_steps
+            loader_state = train_loader.state_dict()   # state from which the prefetched batch is redrawn
             x, y = train_loader.next_batch()   # host work overlaps the queued GPU work
             with timer.phase("backward"):
                 loss.backward()
@@ -183,7 +184,8 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         sink.write(step=it, loss=last_loss, dt_ms=1000 * dt, tokens_per_s=tokens_per_s, mfu=util, lr=lr,
                    mem_gb=mem / 1024 ** 3, peak_flops=PEAK_BF16_DENSE_FLOPS)
         if tc.save_interval and it > 0 and it % tc.save_interval == 0:
-            save_resume(tc.file_name + "_resume", engine, it, (train_loader, val_loader), info.rank, info.world_size)
+            save_resume(tc.file_name + "_resume", engine, it, (train_loader, val_loader), info.rank, info.world_size,
+                        loader_states=[loader_state, val_loader.state_dict()])
 
     if tc.profile and master:
         print(timer.report(), flush=True)

@@ -1,0 +1,79 @@
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from distributed_pytorch_amd.config import LLMconfig, Trainconfig, configs_from_args
+from distributed_pytorch_amd.data import DataLoader, ensure_synthetic, synthetic_tokens
+from distributed_pytorch_amd.trainer import get_lr, train
+
+
+def test_synthetic_tokens_shape():
+    t = synthetic_tokens(50000, 50304)
+    assert t.dtype == np.uint16 and t.max() < 50304 and (t == 50256).sum() > 50
+    assert np.array_equal(t, synthetic_tokens(50000, 50304))
+
+
+def test_loader_semantics_and_rank_sharding(tmp_path):
+    d = ensure_synthetic(str(tmp_path / "syn"), 20000, 1000)
+    single = DataLoader(4, 16, os.path.join(d, "train.bin"), "cpu", 0, 1, seed=5)
+    r0 = DataLoader(2, 16, os.path.join(d, "train.bin"), "cpu", 0, 2, seed=5)
+    r1 = DataLoader(2, 16, os.path.join(d, "train.bin"), "cpu", 1, 2, seed=5)
+    for _ in range(3):
+        x, y = single.next_batch()
+        assert x.shape == (4, 16) and x.dtype == torch.long
+        assert torch.equal(x[:, 1:], y[:, :-1])        # y is x shifted by one
+        x0, y0 = r0.next_batch()
+        x1, y1 = r1.next_batch()
+        assert torch.equal(torch.cat([x0, x1]), x) and torch.equal(torch.cat([y0, y1]), y)
+    with pytest.raises(ValueError):
+        DataLoader(4096, 16, os.path.join(d, "train.bin"), "cpu")
+
+
+def test_lr_schedule_matches_reference_formula():
+    tc = Trainconfig(learning_rate=1e-3, warmup_steps=10, max_iters=100)
+    assert get_lr(0, tc) == pytest.approx(1e-4)
+    assert get_lr(9, tc) == pytest.approx(1e-3)
+    assert get_lr(10, tc) == pytest.approx(1e-3)
+    assert get_lr(102, tc) == pytest.approx(1e-4)
+    assert get_lr(500, tc) == pytest.approx(1e-4)
+    mid = get_lr(56, tc)
+    assert 1e-4 < mid < 1e-3
+
+
+def test_single_trainer_cpu_checkpoint_loads_into_reference(tmp_path, reference_model_module, capsys):
+    """BASELINE config 1: small GPT on the CPU through the single-GPU entry path; the checkpoint
+    it writes loads into the reference LLM with strict=True."""
+    import dataclasses
+    argv = (f"--preset char-10m --n_layer 2 --n_embd 64 --n_head 4 --up_dim 128 --block_size 32 --vocab_size 300 "
+            f"--dataset synthetic --synthetic_tokens 20000 --data_dir {tmp_path / 'd'} --batch_size 2 "
+            f"--total_batch_size_str 2*32*2 --max_iters 6 --eval --eval_interval 3 --eval_iters 2 --warmup_steps 2 "
+            f"--learning_rate 3e-3 --save_model --file_name {tmp_path / 'run'} --metrics_jsonl {tmp_path / 'm.jsonl'}").split()
+    tc, mc = configs_from_args(argv)
+    res = train(tc, mc, mode="single")
+    out = capsys.readouterr().out
+    assert "step: 0 | train loss:" in out and "grad_accum_steps: 2" in out and "val run" in out and "tok/s" in out
+    assert res["losses"][-1] < res["losses"][0]
+    ckpt = torch.load(str(tmp_path / "run_ckpt.pt"), weights_only=False)
+    assert set(ckpt) >= {"model_config", "train_config", "model_state"}
+    ref = reference_model_module
+    names = [f.name for f in dataclasses.fields(ref.LLMconfig)]
+    rm = ref.LLM(ref.LLMconfig(**{n: ckpt["model_config_dict"][n] for n in names}))
+    rm.load_state_dict(ckpt["model_state"], strict=True)
+    stats = torch.load(str(tmp_path / "run_stats.pt"), weights_only=False)
+    assert stats["total_params"] == sum(p.numel() for p in rm.parameters())
+    assert len(open(tmp_path / "m.jsonl").read().strip().splitlines()) == 7
+
+
+def test_resume_continues_identically(tmp_path):
+    base = (f"--n_layer 2 --n_embd 32 --n_head 4 --up_dim 64 --block_size 16 --vocab_size 128 --attn mha --pos_emb learn "
+            f"--non_linearity gelu --dataset synthetic --synthetic_tokens 8000 --data_dir {tmp_path / 'd'} "
+            f"--batch_size 2 --total_batch_size_str 64 --warmup_steps 2 --learning_rate 1e-2")
+    tc, mc = configs_from_args((base + f" --max_iters 6 --file_name {tmp_path / 'a'}").split())
+    full = train(tc, mc, "single")
+    tc, mc = configs_from_args((base + f" --max_iters 6 --save_interval 4 --file_name {tmp_path / 'b'}").split())
+    train(tc, mc, "single")
+    tc, mc = configs_from_args((base + f" --max_iters 6 --resume {tmp_path / 'b_resume'} --file_name {tmp_path / 'c'}").split())
+    resumed = train(tc, mc, "single")
+    assert resumed["losses"] == pytest.approx(full["losses"][5:], rel=1e-5)
