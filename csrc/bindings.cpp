@@ -379,9 +379,75 @@ void rope_(Tensor x, const Tensor& cos_t, const Tensor& sin_t, int64_t pos0, boo
                     cur_stream());
 }
 
+// ---------------------------------------------------------------------------------------
+void check_rows2d(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kBFloat16 && t.dim() == 2 && t.stride(1) == 1, name,
+              ": bf16 [rows, cols] with unit inner stride");
+  TORCH_CHECK(t.stride(0) % 8 == 0 && reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name,
+              ": rows must be 16-byte aligned");
+}
+
+void wgrad_into(const Tensor& dy, const Tensor& x, Tensor ws, const std::optional<Tensor>& dbias) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1);
+  TORCH_CHECK(x.size(0) == M, "wgrad: dy and x must have the same number of rows");
+  TORCH_CHECK(N % 128 == 0 && K % 128 == 0, "wgrad: output dims must be multiples of 128, got ", N, " x ", K);
+  TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.numel() == N * K,
+              "wgrad: workspace must be fp32 [N, K]");
+  float* db = nullptr;
+  if (dbias.has_value()) {
+    TORCH_CHECK(dbias->is_cuda() && dbias->scalar_type() == at::kFloat && dbias->is_contiguous() &&
+                    dbias->numel() == N,
+                "wgrad: dbias must be fp32 [N]");
+    db = dbias->data_ptr<float>();
+  }
+  const int splits = dpa::wgrad_splits((int)M, (int)N, (int)K);
+  dpa::wgrad_gemm(dy.data_ptr(), x.data_ptr(), ws.data_ptr<float>(), db, (int)M, (int)N, (int)K, dy.stride(0),
+                  x.stride(0), splits, cur_stream());
+}
+
+void ws_to(const Tensor& ws, Tensor out, bool accumulate) {
+  TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous(), "ws_to: fp32 workspace");
+  check_act(out, "out");
+  TORCH_CHECK(out.numel() > 0 && ws.numel() % out.numel() == 0 && out.numel() % 8 == 0, "ws_to: size mismatch");
+  dpa::wgrad_finish(ws.data_ptr<float>(), out.data_ptr(), out.numel(), (int)(ws.numel() / out.numel()), accumulate,
+                    is_bf16(out), cur_stream());
+}
+
+// dw [N, K] = dy[M, N]^T x[M, K] through per-split fp32 slabs (no atomics).
+Tensor wgrad2(const Tensor& dy, const Tensor& x) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1);
+  TORCH_CHECK(x.size(0) == M && dpa::wgrad2_ok((int)M, (int)N, (int)K), "wgrad2: unsupported shape ", M, "x", N, "x", K);
+  const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
+  Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
+  dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                   x.stride(0), splits, cur_stream());
+  Tensor dw = at::empty({N, K}, dy.options());
+  dpa::wgrad_finish(slabs.data_ptr<float>(), dw.data_ptr(), N * K, splits, false, true, cur_stream());
+  return dw;
+}
+
+// ws[N, K] (fp32) += dy^T x in one pass over the tokens (accumulation across row chunks).
+void wgrad2_accum(const Tensor& dy, const Tensor& x, Tensor ws) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1);
+  TORCH_CHECK(x.size(0) == M && dpa::wgrad2_ok((int)M, (int)N, (int)K), "wgrad2: unsupported shape ", M, "x", N, "x", K);
+  TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.numel() == N * K);
+  dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), ws.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                   x.stride(0), 0, cur_stream());
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dpa, m) {
+  m.def("wgrad_into(Tensor dy, Tensor x, Tensor(a!) ws, Tensor(b!)? dbias) -> ()");
+  m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
+  m.def("wgrad2(Tensor dy, Tensor x) -> Tensor");
+  m.def("wgrad2_accum(Tensor dy, Tensor x, Tensor(a!) ws) -> ()");
   m.def("layernorm_fwd(Tensor x, Tensor? res, Tensor w, Tensor b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres) -> (Tensor, Tensor, Tensor)");
   m.def("adamw_step(Tensor(a!) master, Tensor(b!) m, Tensor(c!) v, Tensor grad, Tensor? param_out, int[] seg_ends, "
@@ -406,6 +472,10 @@ TORCH_LIBRARY(dpa, m) {
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("wgrad_into", wgrad_into);
+  m.impl("ws_to", ws_to);
+  m.impl("wgrad2", wgrad2);
+  m.impl("wgrad2_accum", wgrad2_accum);
   m.impl("layernorm_fwd", layernorm_fwd);
   m.impl("layernorm_bwd", layernorm_bwd);
   m.impl("adamw_step", adamw_step);

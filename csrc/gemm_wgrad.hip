@@ -1,0 +1,321 @@
+// Weight-gradient GEMM for gfx950:  dW[N, K] (+)= dY[M, N]^T * X[M, K]   (+ dbias[N] = sum_m dY)
+//
+// This is the GEMM shape that the backward pass of every Linear layer needs: the contraction
+// runs over the M = batch*seq tokens (tens of thousands) while the output is a small weight
+// matrix, and BOTH operands are "contraction-strided" (row-major activations, contraction
+// down the rows). Library kernels launch a few dozen workgroups for it and crawl.
+//
+// Design:
+//  * one workgroup = one 128x128 output tile x one slice of the token range (split-M): the grid
+//    is (N/128) * (K/128) * splits workgroups, sized to >= 2 per CU;
+//  * dY and X tiles of 64 tokens x 128 columns are staged row-major into LDS exactly as they
+//    sit in memory (16-byte loads, XOR-swizzled chunks, double-buffered, loads of tile t+1 in
+//    flight during the MFMAs of tile t); both MFMA operands are fetched with the transposed
+//    LDS read (ds_read_b64_tr_b16), so no transposed copy of any activation is ever made;
+//  * each of the 4 waves owns a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators;
+//  * partial tiles are accumulated in an fp32 workspace (plain read-modify-write when the
+//    tile has a single owner, float atomics — whole 128-byte row segments per instruction —
+//    when the token range is split), and a small pass converts / adds into the bf16 gradient;
+//  * the bias gradient (column sums of dY) is folded into the staging pass of the workgroups
+//    of the first K-tile column: the values are already in registers on their way to LDS.
+//
+// Replaces the dW GEMMs that `nn.Linear`'s backward issues implicitly in the reference
+// (reference: single-gpu/model.py:112-114,373-384,559).
+#include "common.h"
+#include "kernels.h"
+#include "mfma_tiles.h"
+
+namespace dpa {
+
+constexpr int kWgTile = 128;   // output tile edge
+constexpr int kWgStep = 64;    // tokens per LDS tile
+
+template <bool ATOMIC, bool BIAS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                    float* __restrict__ ws, float* __restrict__ dbias, int M, int N,
+                                                    int K, long long ldy, long long ldx, int splits, int mper) {
+  constexpr int TILE = kWgStep * kWgTile * 2;  // 16 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int tiles_k = K / kWgTile;
+  const int id = blockIdx.x;
+  const int split = id % splits, tile = id / splits;
+  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  const int n0 = tn * kWgTile, k0 = tk * kWgTile;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int m_begin = split * mper;
+  int m_end = m_begin + mper;
+  if (m_end > M) m_end = M;
+  const int ntiles = (m_end > m_begin) ? (m_end - m_begin + kWgStep - 1) / kWgStep : 0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool do_bias = BIAS && (tk == 0);
+
+  Stage64<128> ys, xs;
+  const bf16_t* yp = dy + n0;
+  const bf16_t* xp = x + k0;
+  auto issue = [&](int t) {
+    ys.issue(yp, m_begin + t * kWgStep, m_end, ldy, tid);
+    xs.issue(xp, m_begin + t * kWgStep, m_end, ldx, tid);
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * 2 * TILE;
+    ys.commit(base, tid);
+    xs.commit(base + TILE, tid);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < Stage64<128>::NLD; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bsum[2 * j] += lo_bf16(ys.reg[i][j]);
+          bsum[2 * j + 1] += hi_bf16(ys.reg[i][j]);
+        }
+    }
+  };
+  if (ntiles > 0) {
+    issue(0);
+    commit(0);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) issue(t + 1);
+    __syncthreads();
+    const char* yb = smem + (t & 1) * 2 * TILE;
+    const char* xb = yb + TILE;
+#pragma unroll
+    for (int s = 0; s < kWgStep / 16; ++s) {
+      bfrag a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = tr_frag<128>(yb, 0, s, 2 * wn + i, lane);
+        b[i] = tr_frag<128>(xb, 0, s, 2 * wk + i, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+    if (t + 1 < ntiles) commit((t + 1) & 1);
+  }
+
+  // accumulate the 64x64 wave tile into the fp32 workspace
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* base = ws + (long long)(n0 + 64 * wn + 32 * i) * K + k0 + 64 * wk + 32 * j + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* p = base + (long long)acc_row(r, hh) * K;
+        if (ATOMIC) atomicAdd(p, acc[i][j][r]);
+        else *p += acc[i][j][r];
+      }
+    }
+  if (do_bias) {
+    // every thread owns the same 8 columns (chunk tid % 16) in all of its staged rows
+    const int c0 = (tid & 15) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(dbias + n0 + c0 + j, bsum[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Second-generation kernel: 128 x 256 output tile, 64-token LDS tiles filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write instructions — at 64 tokens per
+// tile the ds_write_b128 path, ~79 B/clk/CU, is what bounded the register-staged kernel
+// above). The XOR swizzle that the transposed reads need is applied to the per-lane SOURCE
+// address, the LDS image itself is written linearly. Each of the 4 waves owns 128 x 64 of the
+// tile (4 x 2 accumulators: 6 operand fragments feed 8 MFMAs per 16-token step). One LDS
+// buffer of 48 KiB; two or three workgroups per CU overlap each other's DMA waits.
+// Partial results go to per-split fp32 slabs with plain stores (no atomics, bitwise
+// reproducible); the finishing pass sums the slabs.
+// ------------------------------------------------------------------------------------------
+constexpr int kW2N = 128, kW2K = 256;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// DMA a [64 tokens][128 cols] bf16 sub-tile (16 KiB = 16 pieces of 1 KiB) with 4 waves.
+__device__ __forceinline__ void dma_subtile(const bf16_t* g, long long ld, int col_limit, char* lds, int wave,
+                                            int lane) {
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int piece = wave * 4 + pc;
+    const int row = piece * 4 + (lane >> 4);
+    int chunk = swz<128>(row, lane & 15);   // slot -> logical chunk (the swizzle is an involution)
+    if (chunk * 8 >= col_limit) chunk = 0;  // columns past the matrix edge: any valid address, never stored
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (long long)row * ld + chunk * 8), (lptr_t)(lds + piece * 1024), 16,
+                                     0, 0);
+  }
+}
+
+template <bool ACCUM>
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                        float* __restrict__ slabs, int M, int N, int K, long long ldy,
+                                                        long long ldx, int splits, int mper) {
+  constexpr int SUB = 64 * 128 * 2;  // 16 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int tiles_k = K / kW2K;
+  const int id = blockIdx.x;
+  const int split = id % splits, tile = id / splits;
+  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  const int n0 = tn * kW2N, k0 = tk * kW2K;
+  const int m_begin = split * mper;
+  int m_end = m_begin + mper;
+  if (m_end > M) m_end = M;
+  const int ntiles = (m_end > m_begin) ? (m_end - m_begin) / 64 : 0;   // M % 64 == 0 (host-checked)
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  char* ya = smem;            // dY sub-tile  [64][128]
+  char* xa = smem + SUB;      // X sub-tiles  [64][128] x 2
+  for (int t = 0; t < ntiles; ++t) {
+    const long long m = m_begin + t * 64;
+    __syncthreads();          // everybody is done reading the previous tile
+    dma_subtile(dy + m * ldy + n0, ldy, N - n0, ya, wave, lane);
+    dma_subtile(x + m * ldx + k0, ldx, K - k0, xa, wave, lane);
+    dma_subtile(x + m * ldx + k0 + 128, ldx, K - k0 - 128, xa + SUB, wave, lane);
+    __syncthreads();          // waits for this wave's DMA (vmcnt) and for everybody else's
+    const char* xb = xa + (wave >> 1) * SUB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bfrag a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = tr_frag<128>(ya, 0, s, i, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = tr_frag<128>(xb, 0, s, 2 * (wave & 1) + j, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+  }
+
+  float* out = slabs + (ACCUM ? 0 : (long long)split * N * K);
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = k0 + 64 * wave + 32 * j + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * i + acc_row(r, hh);
+        if (n < N && kk < K) {
+          float* p = out + (long long)n * K + kk;
+          if (ACCUM) *p += acc[i][j][r];
+          else *p = acc[i][j][r];
+        }
+      }
+    }
+}
+
+// out (bf16 or fp32) = [out +] sum over `nslabs` slabs of ws
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ ws, T* __restrict__ out,
+                                                           long long nvec, int nslabs, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    float a[8];
+    load8(ws + i * 8, a);
+    for (int s = 1; s < nslabs; ++s) {
+      float b[8];
+      load8(ws + (long long)s * nvec * 8 + i * 8, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += b[j];
+    }
+    if (accumulate) {
+      float o[8];
+      load8(out + i * 8, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += o[j];
+    }
+    store8(out + i * 8, a);
+  }
+}
+
+int wgrad_splits(int M, int N, int K) {
+  const int tiles = (N / kWgTile) * (K / kWgTile);
+  int s = (512 + tiles - 1) / tiles;          // aim at >= 2 workgroups per CU
+  const int max_s = (M + 4 * kWgStep - 1) / (4 * kWgStep);   // at least 4 LDS tiles per workgroup
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+
+void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, int N, int K, long long ldy,
+                long long ldx, int splits, hipStream_t st) {
+  if (M == 0) return;
+  int mper = (M + splits - 1) / splits;
+  mper = (mper + kWgStep - 1) / kWgStep * kWgStep;
+  const dim3 grid((N / kWgTile) * (K / kWgTile) * splits), block(256);
+  const size_t lds = 4 * kWgStep * kWgTile * 2;  // 64 KiB
+#define DPA_WG(A, B)                                                                                            \
+  hipLaunchKernelGGL((wgrad_kernel<A, B>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, dbias, M, \
+                     N, K, ldy, ldx, splits, mper)
+  if (splits > 1) {
+    if (dbias) DPA_WG(true, true); else DPA_WG(true, false);
+  } else {
+    if (dbias) DPA_WG(false, true); else DPA_WG(false, false);
+  }
+#undef DPA_WG
+}
+
+bool wgrad2_ok(int M, int N, int K) { return M % 64 == 0 && M >= 64 && N % 8 == 0 && K % kW2K == 0; }
+
+int wgrad2_splits(int M, int N, int K) {
+  const int tiles = ((N + kW2N - 1) / kW2N) * (K / kW2K);
+  int s = 512 / tiles;                 // two workgroups per CU in a single round
+  const int max_s = M / 256;           // at least 4 LDS tiles per workgroup
+  if (s > max_s) s = max_s;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+
+// splits > 0: writes `splits` slabs (ws holds splits*N*K floats). splits == 0: a single pass
+// over all tokens that ADDS into ws[N*K] (accumulation across calls, e.g. lm_head row chunks).
+void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
+                 int splits, hipStream_t st) {
+  if (M == 0) return;
+  const int sp = splits > 0 ? splits : 1;
+  int mper = (M / 64 + sp - 1) / sp * 64;
+  const dim3 grid(((N + kW2N - 1) / kW2N) * (K / kW2K) * sp), block(256);
+  const size_t lds = 3 * 64 * 128 * 2;  // 48 KiB
+  if (splits > 0)
+    hipLaunchKernelGGL((wgrad2_kernel<false>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
+                       ldy, ldx, sp, mper);
+  else
+    hipLaunchKernelGGL((wgrad2_kernel<true>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
+                       ldy, ldx, 1, mper);
+}
+
+void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
+                  hipStream_t st) {
+  const long long nvec = n >> 3;
+  if (nvec == 0) return;
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (out_bf16)
+    hipLaunchKernelGGL((wgrad_finish_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, ws, (bf16_t*)out, nvec,
+                       nslabs, accumulate ? 1 : 0);
+  else
+    hipLaunchKernelGGL((wgrad_finish_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, ws, (float*)out, nvec,
+                       nslabs, accumulate ? 1 : 0);
+}
+
+}  // namespace dpa

@@ -65,6 +65,22 @@ struct AttnParams {
 void attn_fwd(const AttnParams& p, hipStream_t st);
 void attn_bwd(const AttnParams& p, hipStream_t st);
 
+// ---- Weight-gradient GEMM -----------------------------------------------------------------
+// ws[N, K] (fp32) += dy[M, N]^T * x[M, K]; dbias[N] (fp32, optional) += column sums of dy.
+// N and K must be multiples of 128; rows 16-byte aligned. With splits > 1 the token range is
+// divided over workgroups that combine through float atomics.
+int wgrad_splits(int M, int N, int K);
+void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, int N, int K, long long ldy,
+                long long ldx, int splits, hipStream_t st);
+// LDS-DMA version (K % 256 == 0, M % 64 == 0). splits > 0: `splits` fp32 slabs are written;
+// splits == 0: one pass that adds into ws[N*K].
+bool wgrad2_ok(int M, int N, int K);
+int wgrad2_splits(int M, int N, int K);
+void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
+                 int splits, hipStream_t st);
+void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
+                  hipStream_t st);
+
 // ---- RoPE -------------------------------------------------------------------------------
 // In-place interleaved-pair rotation of `nheads` heads of size hs at x + t*ts (+ b*bs), using
 // fp32 cos/sin tables [T_total, hs/2] starting at row pos0. `inverse` applies the transpose

@@ -91,7 +91,7 @@ class GQA(nn.Module):
         B, T, C = x.shape
         nh, nkv, hs = self.config.n_head, self.config.n_kv_heads, self.head_size
         p_drop = self.config.dropout if self.training else 0.0
-        qkv = F.linear(x, self.c_attn.weight, self.c_attn.bias)
+        qkv = ops.linear(x, self.c_attn.weight, self.c_attn.bias)
         if rope is not None:
             # rotate the q and k heads (contiguous leading part of the fused projection)
             cos_t, sin_t, pos0 = rope
@@ -109,7 +109,7 @@ class GQA(nn.Module):
             y = ops.causal_attention(q, k, v, dropout_p=p_drop)
             new_cache = (k.transpose(1, 2), v.transpose(1, 2))  # reference cache shape (B, nkv, T, hs)
         y = y.reshape(B, T, C)
-        y = _drop(F.linear(y, self.c_proj.weight, self.c_proj.bias), self.config.dropout, self.training)
+        y = _drop(ops.linear(y, self.c_proj.weight, self.c_proj.bias), self.config.dropout, self.training)
         return y, new_cache
 
     def _want_cache(self) -> bool:
@@ -167,9 +167,9 @@ class NaiveMHLA(nn.Module):
                     k_abs, v_abs = self._absorbed()
                     self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
             k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
-        new_c_kv = F.linear(x, self.W_dkv.weight)
+        new_c_kv = ops.linear(x, self.W_dkv.weight)
         c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache, new_c_kv], dim=1)
-        q = F.linear(F.linear(x, self.W_dq.weight), self.W_uq.weight).view(B, T, nh, hs)
+        q = ops.linear(ops.linear(x, self.W_dq.weight), self.W_uq.weight).view(B, T, nh, hs)
         q_eff = torch.einsum("bthd,hdl->bthl", q, k_abs.to(q.dtype))          # (B, T, nh, n_kvl)
         ctx = _mla_attention(q_eff, c_kv.unsqueeze(2), c_kv.unsqueeze(2), 1.0 / math.sqrt(hs), p_drop)
         y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
@@ -213,7 +213,7 @@ class FullMHLA(nn.Module):
         hs, dhr = self.head_size, self.config.rope_head_dim
         p_drop = self.config.dropout if self.training else 0.0
         cos_t, sin_t, pos0 = rope
-        c_q = F.linear(x, self.W_dq.weight)                                   # (B, T, nlq)
+        c_q = ops.linear(x, self.W_dq.weight)                                   # (B, T, nlq)
         if self.training or VAL_RUN:
             k_abs, v_abs = self._absorbed()
         else:
@@ -222,13 +222,13 @@ class FullMHLA(nn.Module):
                     k_abs, v_abs = self._absorbed()
                     self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
             k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
-        new_c_kv = F.linear(x, self.W_dkv.weight)
+        new_c_kv = ops.linear(x, self.W_dkv.weight)
         c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache["c_kv"], new_c_kv], dim=1)
-        k_r = ops.apply_rope(F.linear(x, self.W_kr.weight).view(B, T, 1, dhr), cos_t, sin_t, pos0)
+        k_r = ops.apply_rope(ops.linear(x, self.W_kr.weight).view(B, T, 1, dhr), cos_t, sin_t, pos0)
         k_r = k_r.transpose(1, 2)                                              # (B, 1, T, dhr): cache layout
         if kv_cache is not None:
             k_r = torch.cat([kv_cache["k_r"], k_r], dim=2)
-        q_r = ops.apply_rope(F.linear(c_q, self.W_qr.weight).view(B, T, nh, dhr), cos_t, sin_t, pos0)
+        q_r = ops.apply_rope(ops.linear(c_q, self.W_qr.weight).view(B, T, nh, dhr), cos_t, sin_t, pos0)
         q_nope = torch.einsum("btq,hql->bthl", c_q, k_abs.to(c_q.dtype))       # (B, T, nh, nlkv)
         q_eff = torch.cat([q_nope, q_r], dim=-1)                               # (B, T, nh, nlkv + dhr)
         k_eff = torch.cat([c_kv, k_r.squeeze(1)], dim=-1).unsqueeze(2)         # (B, Tk, 1, nlkv + dhr)
@@ -274,9 +274,9 @@ class MLP(nn.Module):
         self.p_drop = config.dropout
 
     def forward(self, x):
-        h = F.linear(x, self.c_fc.weight)
+        h = ops.linear(x, self.c_fc.weight)
         h = ops.swiglu(h) if self.non_linearity == "swiglu" else self._act(h)
-        return _drop(F.linear(h, self.c_proj.weight), self.p_drop, self.training)
+        return _drop(ops.linear(h, self.c_proj.weight), self.p_drop, self.training)
 
 
 class Expert(nn.Module):
@@ -315,7 +315,7 @@ class MoE(nn.Module):
         """-> (topk_indices [N,k], topk_gates [N,k], aux_loss)."""
         cfg = self.config
         n_tokens = x_flat.shape[0]
-        router_logits = F.linear(x_flat, self.gate.weight).float()
+        router_logits = ops.linear(x_flat, self.gate.weight).float()
         if cfg.aux_free:
             biased = router_logits + self.expert_bias.float()
             _, topk_indices = torch.topk(biased, self.n_act_routed, dim=1)
@@ -544,13 +544,13 @@ class LLM(nn.Module):
         if targets is not None:
             logits = None
             if self.materialize_logits:
-                logits = F.linear(x, wte)
+                logits = ops.linear(x, wte)
                 main_loss = ops.cross_entropy(logits, targets)
             else:
                 main_loss = ops.linear_cross_entropy(x, wte, targets, chunk_rows=self.loss_chunk_rows)
             loss = main_loss + total_aux / cfg.n_layer
         else:
-            logits = F.linear(x[:, [-1], :], wte)
+            logits = ops.linear(x[:, [-1], :], wte)
             loss = None
         return logits, loss, new_caches
 

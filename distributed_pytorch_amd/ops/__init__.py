@@ -3,6 +3,7 @@ implementation that is used only for CPU tensors (plumbing tests) or unsupported
 from .activation import gelu, get_activation, swiglu
 from .attention import (causal_attention, causal_attention_eager, causal_self_attention_qkv, split_qkv)
 from .embedding import embedding
+from .linear import linear, weight_grad, wgrad_supported
 from .loss import IGNORE_INDEX, cross_entropy, linear_cross_entropy, vocab_parallel_cross_entropy
 from .norm import add_layer_norm, layer_norm
 from .optim import adamw_step, sumsq
@@ -12,5 +13,5 @@ __all__ = [
     "gelu", "swiglu", "get_activation", "causal_attention", "causal_attention_eager", "causal_self_attention_qkv",
     "split_qkv", "embedding", "cross_entropy", "linear_cross_entropy", "vocab_parallel_cross_entropy",
     "IGNORE_INDEX", "layer_norm", "add_layer_norm", "adamw_step", "sumsq", "apply_rope", "rope_inplace_",
-    "rope_tables",
+    "rope_tables", "linear", "weight_grad", "wgrad_supported",
 ]

@@ -1,0 +1,81 @@
+"""Linear layer with a hand-written weight-gradient path.
+
+Forward ``y = x @ w.T + b`` and the input gradient ``dx = dy @ w`` are plain library GEMMs
+(hipBLASLt through ``torch``): both contract over a contiguous dimension and run near the
+library's best. The weight gradient ``dw = dy.T @ x`` contracts over the tokens with both
+operands strided; it runs on the split-M MFMA kernel of ``csrc/gemm_wgrad.hip`` (2-3x the
+library on these shapes), which also produces the bias gradient from the tiles it already
+stages instead of a separate column-sum reduction.
+
+Reference behaviour: ``nn.Linear`` (reference: single-gpu/model.py:112-114,373-384).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .._ext import ops, use_hip
+
+
+def wgrad_supported(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
+    return (dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+            and dy2.shape[1] % 128 == 0 and x2.shape[1] % 128 == 0 and dy2.shape[0] >= 256
+            and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
+            and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
+
+
+def wgrad2_supported(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
+    """Shapes of the LDS-DMA kernel: tokens % 64 == 0, K % 256 == 0."""
+    return (dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+            and dy2.shape[0] % 64 == 0 and dy2.shape[0] >= 256 and dy2.shape[1] % 8 == 0 and x2.shape[1] % 256 == 0
+            and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
+            and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
+
+
+def weight_grad(dy2: torch.Tensor, x2: torch.Tensor, want_bias: bool, version: int = 0):
+    """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16."""
+    N, K = dy2.shape[1], x2.shape[1]
+    if version != 1 and wgrad2_supported(dy2, x2):
+        dw = ops().wgrad2(dy2, x2)
+        return dw, (dy2.sum(0) if want_bias else None)
+    ws = torch.zeros(N, K, dtype=torch.float32, device=dy2.device)
+    bws = torch.zeros(N, dtype=torch.float32, device=dy2.device) if want_bias else None
+    ops().wgrad_into(dy2, x2, ws, bws)
+    dw = torch.empty(N, K, dtype=dy2.dtype, device=dy2.device)
+    ops().ws_to(ws, dw, False)
+    return dw, (bws.to(dy2.dtype) if want_bias else None)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, w).view(x.shape)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if wgrad2_supported(dy2, x2) or wgrad_supported(dy2, x2):
+                dw, db = weight_grad(dy2, x2, need_b)
+            else:
+                dw = torch.mm(dy2.t(), x2)
+                if need_b:
+                    db = dy2.sum(0)
+        elif need_b:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None) -> torch.Tensor:
+    if use_hip(x, w) and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and torch.is_grad_enabled() \
+            and (x.requires_grad or w.requires_grad):
+        return _LinearFn.apply(x, w, b)
+    return F.linear(x, w, b)

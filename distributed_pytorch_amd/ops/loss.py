@@ -76,6 +76,9 @@ class _LinearXentFn(torch.autograd.Function):
         loss_acc = torch.zeros((), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if need_dx else None
         dw = None
+        # weight gradient: fp32 accumulation across the row chunks on the split-M MFMA kernel
+        use_wg = need_dw and x.dtype == torch.bfloat16 and V % 128 == 0 and C % 128 == 0
+        ws = torch.zeros(V, C, dtype=torch.float32, device=x.device) if use_wg else None
         logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
         for r0 in range(0, N, chunk_rows):
             r1 = min(N, r0 + chunk_rows)
@@ -87,10 +90,19 @@ class _LinearXentFn(torch.autograd.Function):
             if need_dx:
                 torch.mm(lg, w, out=dx[r0:r1])
             if need_dw:
-                if dw is None:
+                if use_wg and (r1 - r0) % 64 == 0 and C % 256 == 0 and r1 - r0 >= 256:
+                    ops().wgrad2_accum(lg, xc, ws)
+                elif use_wg and r1 - r0 >= 256:
+                    ops().wgrad_into(lg, xc, ws, None)
+                elif use_wg:
+                    ws.addmm_(lg.t().float(), xc.float())
+                elif dw is None:
                     dw = torch.mm(lg.t(), xc)
                 else:
                     dw.addmm_(lg.t(), xc)
+        if use_wg:
+            dw = torch.empty(V, C, dtype=x.dtype, device=x.device)
+            ops().ws_to(ws, dw, False)
         ctx.save_for_backward(dx, dw)
         return loss_acc * gs[0]
 

@@ -294,3 +294,53 @@ def test_flash_attention_fused_qkv_and_spike():
     orf.backward(g.float())
     assert rel_err(o, orf) < 1e-2
     assert rel_err(qkv.grad, ref_in.grad) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(4096, 768, 3072, False), (32768, 2304, 768, True), (1000, 128, 256, True),
+                                        (8192, 768, 768, True), (300, 256, 128, False)])
+def test_wgrad_gemm(M, N, K, bias):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(10)
+    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    dw, db = ops.weight_grad(dy, x, bias, version=1)
+    want = dy.float().t() @ x.float()
+    assert rel_err(dw, want) < 5e-3
+    if bias:
+        assert rel_err(db, dy.float().sum(0)) < 5e-3
+    else:
+        assert db is None
+
+
+def test_linear_autograd_matches_reference():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(11)
+    x = torch.randn(4, 256, 768, device=DEV).to(torch.bfloat16).requires_grad_()
+    w = (torch.randn(2304, 768, device=DEV) * 0.02).to(torch.bfloat16).requires_grad_()
+    b = torch.randn(2304, device=DEV).to(torch.bfloat16).requires_grad_()
+    y = ops.linear(x, w, b)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr, wr, br = [t.detach().float().requires_grad_() for t in (x, w, b)]
+    yr = F.linear(xr, wr, br)
+    yr.backward(g.float())
+    assert rel_err(y, yr) < 1e-2 and rel_err(x.grad, xr.grad) < 1e-2
+    assert rel_err(w.grad, wr.grad) < 1e-2 and rel_err(b.grad, br.grad) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 3072), (32768, 2304, 768), (1024, 200, 256), (8192, 50304, 768),
+                                   (320, 128, 512)])
+def test_wgrad2_gemm(M, N, K):
+    """LDS-DMA weight-gradient kernel, incl. an output height that is not a multiple of the tile."""
+    from distributed_pytorch_amd import ops
+    from distributed_pytorch_amd._ext import ops as hip
+    torch.manual_seed(12)
+    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    assert ops.linear.__module__ and ops.wgrad_supported is not None
+    dw = hip().wgrad2(dy, x)
+    want = dy.float().t() @ x.float()
+    assert rel_err(dw, want) < 5e-3
+    ws = torch.ones(N, K, device=DEV)
+    hip().wgrad2_accum(dy, x, ws)
+    assert rel_err(ws, want + 1.0) < 5e-3

@@ -1,0 +1,97 @@
+"""End-to-end checks on the MI355X: the bf16 HIP path against the fp32 eager path of the same
+model, every engine type stepping on the GPU, and the HIP extension actually being used."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from distributed_pytorch_amd.config import LLMconfig
+from distributed_pytorch_amd.models.llm import LLM
+
+BASE = dict(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512)
+VARIANTS = {
+    "gpt2": dict(attn="mha", pos_emb="learn", non_linearity="gelu"),
+    "gqa_rope_swiglu": dict(attn="gqa", n_kv_heads=2, pos_emb="rope", non_linearity="swiglu"),
+    "mqa_sin": dict(attn="mqa", pos_emb="sin", non_linearity="relu"),
+    "mla_rope_flash": dict(attn="mla", pos_emb="rope", q_latent_dim=64, kv_latent_dim=96, rope_head_dim=32),
+    "mla_naive_flash": dict(attn="mla", pos_emb="learn", q_latent_dim=64, kv_latent_dim=64),
+    "moe": dict(attn="mha", pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2),
+    "recompute": dict(attn="mha", pos_emb="learn", non_linearity="gelu", act_recomp=True),
+}
+
+
+def test_extension_loaded():
+    from distributed_pytorch_amd import _ext
+    assert _ext.available(), "the in-tree HIP extension must load on the GPU box"
+    assert hasattr(torch.ops.dpa, "attn_fwd") and hasattr(torch.ops.dpa, "wgrad2")
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_bf16_hip_matches_fp32_eager(name):
+    from distributed_pytorch_amd.parallel.engine import Engine
+    torch.manual_seed(0)
+    cfg = LLMconfig(**BASE, **VARIANTS[name]).finalize()
+    ref = LLM(cfg)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    idx = torch.randint(0, cfg.vocab_size, (4, 256))
+    tgt = torch.randint(0, cfg.vocab_size, (4, 256))
+    _, want, _ = ref(idx, tgt)
+    want.backward()
+    gref = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    torch.manual_seed(0)
+    model = LLM(cfg)
+    model.load_state_dict(sd)
+    eng = Engine(model, dtype="bf16", device="cuda:0")
+    eng.zero_grad()
+    _, got, _ = eng(idx.cuda(), tgt.cuda())
+    got.backward()
+    assert abs(got.item() - want.item()) < 3e-2 * abs(want.item())
+    # gradient direction agrees (bf16 vs fp32): cosine similarity over the big tensors
+    for n, p in eng.module.named_parameters():
+        if p.numel() >= 4096 and "gate" not in n:
+            a, b = p.grad.float().flatten().cpu(), gref[n].flatten()
+            cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+            assert cos > 0.98, f"{name}: grad of {n} diverges (cos {cos:.4f})"
+
+
+@pytest.mark.parametrize("mode", ["single", "ddp", "zero1", "zero2", "fsdp"])
+def test_every_engine_trains_on_gpu(mode):
+    from distributed_pytorch_amd.config import Trainconfig
+    from distributed_pytorch_amd.parallel import comm
+    from distributed_pytorch_amd.trainer import build_engine
+    torch.manual_seed(1)
+    cfg = LLMconfig(**BASE, **VARIANTS["gpt2"]).finalize()
+    info = comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "none")
+    eng = build_engine(mode, LLM(cfg), Trainconfig(dtype="bf16", learning_rate=1e-3), info)
+    x = torch.randint(0, cfg.vocab_size, (8, 256), device="cuda")
+    losses = []
+    for it in range(8):
+        eng.zero_grad()
+        for micro in range(2):
+            eng.require_backward_grad_sync = micro == 1
+            _, loss, _ = eng(x, x.roll(-1, 1))
+            (loss / 2).backward()
+        eng.clip_grad_norm_(1.0)
+        eng.step(3e-3)
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 0.5, f"{mode}: {losses}"
+    sd = eng.state_dict()
+    assert sd["lm_head.weight"].dtype == torch.float32 and sd["lm_head.weight"].shape == (1024, 256)
+
+
+def test_generate_on_gpu_matches_full_forward():
+    torch.manual_seed(2)
+    cfg = LLMconfig(**BASE, **VARIANTS["gqa_rope_swiglu"]).finalize()
+    m = LLM(cfg).cuda().to(torch.bfloat16).eval()
+    # complex buffer must stay complex after .to(bf16)? regenerate tables instead of relying on the cast
+    idx = torch.randint(0, cfg.vocab_size, (2, 40), device="cuda")
+    with torch.no_grad():
+        logits, _, caches = m(idx[:, :32])
+        for t in range(32, 40):
+            logits, _, caches = m(idx[:, t:t + 1], kv_caches=caches)
+        full, _, _ = m(idx)
+    assert torch.allclose(logits[:, -1].float(), full[:, -1].float(), rtol=5e-2, atol=5e-2)
+    out = m.generate(idx[:, :8], max_new_tokens=16, topk=1)
+    assert out.shape == (2, 24)
