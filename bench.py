@@ -33,7 +33,7 @@ from distributed_pytorch_amd.utils.metrics import PEAK_BF16_DENSE_FLOPS, mfu, mo
 # tokens/s of the reference's own single-GPU trainer loop (eager PyTorch, bf16 autocast, fused
 # AdamW, no torch.compile: there is no Triton on this image) for GPT-2-124M at micro-batch 16 on
 # one MI355X, measured with benchmarks/reference_baseline.py. None until measured.
-REFERENCE_TOKENS_PER_S_PER_GPU = None
+REFERENCE_TOKENS_PER_S_PER_GPU = 446_660.0   # micro-batch 32 (409_953 at micro-batch 16)
 
 
 def main():

@@ -24,6 +24,11 @@ CSRC = ROOT / "csrc"
 OBJ = ROOT / "build" / "obj"
 OUT = ROOT / "distributed_pytorch_amd" / "_C.so"
 ARCH = "gfx950"
+# Per-file code generation options. Keeping MFMA accumulators in architectural VGPRs avoids the
+# v_accvgpr_read/write traffic that VALU work on accumulators (softmax rescale, dS) otherwise pays.
+EXTRA_FLAGS = {
+    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
 
 
 def _hipcc() -> str:
@@ -59,7 +64,7 @@ def _run(cmd):
 def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
     OBJ.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
-    headers = sorted(CSRC.glob("*.h"))
+    headers = sorted(CSRC.glob("*.h")) + [Path(__file__).resolve()]
     incs, torch_lib = _torch_paths()
     common = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
               f"-I{CSRC}", "-Wno-unused-result"]
@@ -69,7 +74,7 @@ def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
         obj = OBJ / (src.stem + ".o")
         objs.append(obj)
         if force or _stale(src, obj, headers):
-            cmd = [hipcc, *common, "-c", str(src), "-o", str(obj)]
+            cmd = [hipcc, *common, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
             if asm:
                 (ROOT / "build" / "asm").mkdir(parents=True, exist_ok=True)
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]

@@ -54,6 +54,7 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kDefer = 6.0f;   // deferred-rescale threshold of the forward, in log2 units
 
 // ------------------------------------------------------------------------------------------
 // Forward
@@ -133,9 +134,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[sub][i]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-      const float mc = m_new * c;
+      // Deferred rescale: the running maximum only moves (and O, l are only rescaled) when some
+      // row's tile maximum exceeds it by more than kDefer in the exponent; until then the
+      // probabilities are bounded by 2^kDefer instead of 1, which fp32 accumulation and the
+      // bf16 P operand (same relative precision at any magnitude) absorb. The decision is
+      // wave-uniform, taken before this tile's P is formed and after the previous tile's P*V
+      // has been issued, so everything at the old scale is rescaled exactly once.
+      if (!__all((mx - m) * c <= kDefer)) {
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+        l *= alpha;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+      }
+      const float mc = m * c;
       float rs = 0.f;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
@@ -145,12 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           s[sub][i] = pv;
           rs += pv;
         }
-      l = l * alpha + rs;
-      m = m_new;
-#pragma unroll
-      for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+      l += rs;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll

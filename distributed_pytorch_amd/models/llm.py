@@ -451,6 +451,19 @@ class LLM(nn.Module):
         self._pos_cache = None
 
     # ---- construction helpers -------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        """``.to(bf16)`` / ``.half()`` must not degrade the rotary tables (fp32 cos/sin, complex64
+        ``freqs_cis``): rebuild them on whatever device the weights end up on."""
+        super()._apply(fn, recurse)
+        if self.config.pos_emb == "rope" and self.rope_cos is not None:
+            dev = self.lm_head.weight.device
+            if (self.rope_cos.dtype != torch.float32 or not self.freqs_cis.is_complex()) and dev.type != "meta":
+                d = self.rope_cos.shape[1] * 2
+                cos_t, sin_t = ops.rope_tables(self.config.block_size, d, device=dev)
+                self.rope_cos, self.rope_sin = cos_t, sin_t
+                self.freqs_cis = torch.complex(cos_t, sin_t)
+        return self
+
     def _init_weights(self, module):
         if isinstance(module, nn.Linear):
             torch.nn.init.normal_(module.weight, mean=0.0, std=0.02)

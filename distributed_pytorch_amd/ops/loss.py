@@ -76,8 +76,10 @@ class _LinearXentFn(torch.autograd.Function):
         loss_acc = torch.zeros((), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if need_dx else None
         dw = None
-        # weight gradient: fp32 accumulation across the row chunks on the split-M MFMA kernel
-        use_wg = need_dw and x.dtype == torch.bfloat16 and V % 128 == 0 and C % 128 == 0
+        # weight gradient: per-chunk library GEMM (for a [V, C] output the library's large-tile
+        # kernels are at their best) accumulated across the row chunks in fp32
+        nchunks = (N + chunk_rows - 1) // chunk_rows
+        use_wg = need_dw and x.dtype == torch.bfloat16 and nchunks > 1
         ws = torch.zeros(V, C, dtype=torch.float32, device=x.device) if use_wg else None
         logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
         for r0 in range(0, N, chunk_rows):
@@ -90,19 +92,14 @@ class _LinearXentFn(torch.autograd.Function):
             if need_dx:
                 torch.mm(lg, w, out=dx[r0:r1])
             if need_dw:
-                if use_wg and (r1 - r0) % 64 == 0 and C % 256 == 0 and r1 - r0 >= 256:
-                    ops().wgrad2_accum(lg, xc, ws)
-                elif use_wg and r1 - r0 >= 256:
-                    ops().wgrad_into(lg, xc, ws, None)
-                elif use_wg:
-                    ws.addmm_(lg.t().float(), xc.float())
+                if use_wg:
+                    ws.add_(torch.mm(lg.t(), xc))
                 elif dw is None:
                     dw = torch.mm(lg.t(), xc)
                 else:
                     dw.addmm_(lg.t(), xc)
         if use_wg:
-            dw = torch.empty(V, C, dtype=x.dtype, device=x.device)
-            ops().ws_to(ws, dw, False)
+            dw = ws.to(x.dtype)
         ctx.save_for_backward(dx, dw)
         return loss_acc * gs[0]
 

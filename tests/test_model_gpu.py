@@ -85,7 +85,7 @@ def test_generate_on_gpu_matches_full_forward():
     torch.manual_seed(2)
     cfg = LLMconfig(**BASE, **VARIANTS["gqa_rope_swiglu"]).finalize()
     m = LLM(cfg).cuda().to(torch.bfloat16).eval()
-    # complex buffer must stay complex after .to(bf16)? regenerate tables instead of relying on the cast
+    assert m.rope_cos.dtype == torch.float32 and m.freqs_cis.is_complex()   # tables survive the cast
     idx = torch.randint(0, cfg.vocab_size, (2, 40), device="cuda")
     with torch.no_grad():
         logits, _, caches = m(idx[:, :32])
