@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", type=str, default="ddp", choices=["single", "ddp", "zero1", "zero2", "fsdp"])
     ap.add_argument("--model", type=str, default="gpt2-124m", choices=sorted(PRESETS))
-    ap.add_argument("--batch", type=int, default=32, help="micro-batch (sequences) per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="micro-batch (sequences) per GPU")
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--bucket_mb", type=float, default=48.0)
