@@ -79,15 +79,15 @@ def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
                 (ROOT / "build" / "asm").mkdir(parents=True, exist_ok=True)
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
             jobs.append(cmd)
-    bsrc = CSRC / "bindings.cpp"
-    bobj = OBJ / "bindings.o"
-    objs.append(bobj)
-    if force or _stale(bsrc, bobj, headers):
-        cmd = [hipcc, *common, "-x", "hip", "-DTORCH_EXTENSION_NAME=_C", "-D_GLIBCXX_USE_CXX11_ABI=1"]
-        for i in incs:
-            cmd += ["-isystem", i]
-        cmd += ["-c", str(bsrc), "-o", str(bobj)]
-        jobs.append(cmd)
+    for bsrc in sorted(CSRC.glob("*.cpp")):      # translation units that include PyTorch headers
+        bobj = OBJ / (bsrc.stem + ".o")
+        objs.append(bobj)
+        if force or _stale(bsrc, bobj, headers):
+            cmd = [hipcc, *common, "-x", "hip", "-DTORCH_EXTENSION_NAME=_C", "-D_GLIBCXX_USE_CXX11_ABI=1"]
+            for i in incs:
+                cmd += ["-isystem", i]
+            cmd += ["-c", str(bsrc), "-o", str(bobj)]
+            jobs.append(cmd)
     if jobs:
         if verbose:
             print(f"[build] compiling {len(jobs)} translation unit(s) for {ARCH}", flush=True)

@@ -35,6 +35,13 @@ class DataLoader:
         self.rank, self.world = rank, world
         self.tokens = np.memmap(self.file_path, dtype=np.uint16, mode="r")
         self.N = len(self.tokens)
+        self._native = None
+        try:   # native mmap reader + threaded batch assembly (csrc/dataloader.cpp) when the extension is built
+            from . import _ext
+            if _ext.load():
+                self._native = torch.classes.dpa.TokenFile(self.file_path)
+        except Exception:
+            self._native = None
         if self.B * self.T + 1 > self.N:
             raise ValueError(f"Batch size {B} and block size {T} are too large for dataset of length {self.N}")
         self.gen = torch.Generator()
@@ -62,11 +69,14 @@ class DataLoader:
             self._flip ^= 1
         else:
             buf = torch.empty(2, B, T, dtype=torch.long)
-        arr = buf.numpy()
-        for i, s in enumerate(starts):
-            w = self.tokens[s:s + T + 1]
-            arr[0, i] = w[:-1]
-            arr[1, i] = w[1:]
+        if self._native is not None:
+            self._native.gather(torch.from_numpy(np.ascontiguousarray(starts)), T, buf, 1 if B * T <= (1 << 20) else 4)
+        else:
+            arr = buf.numpy()
+            for i, s in enumerate(starts):
+                w = self.tokens[s:s + T + 1]
+                arr[0, i] = w[:-1]
+                arr[1, i] = w[1:]
         if self.device.type == "cuda":
             dev = buf.to(self.device, non_blocking=True)
             return dev[0], dev[1]
