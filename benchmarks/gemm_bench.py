@@ -3,7 +3,8 @@ GPT-2 shapes. Interleaved rounds in one process, random operands, median over ro
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from distributed_pytorch_amd import ops
+from distributed_pytorch_amd import ops, _ext
+_ext.require()
 
 def timeit(fn, n=20):
     for _ in range(3): fn()
@@ -22,8 +23,15 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (50304, 768)]:
     dy = torch.randn(Mx, N, device="cuda").to(torch.bfloat16)
     x = torch.randn(Mx, K, device="cuda").to(torch.bfloat16)
     fl = 2.0 * Mx * N * K
+    torch.ops.dpa.wgrad2_set_stages(3)
+    err = ((ops.weight_grad(dy, x, False)[0].float() - dy.float().t() @ x.float()).norm() / (dy.float().t() @ x.float()).norm()).item()
+    assert err < 5e-3, err
     t_lib = timeit(lambda: torch.mm(dy.t(), x))
     t_v1 = timeit(lambda: ops.weight_grad(dy, x, False, version=1))
+    torch.ops.dpa.wgrad2_set_stages(1)
     t_v2 = timeit(lambda: ops.weight_grad(dy, x, False))
+    torch.ops.dpa.wgrad2_set_stages(3)
+    t_v3 = timeit(lambda: ops.weight_grad(dy, x, False))
+    torch.ops.dpa.wgrad2_set_stages(1)
     print(f"dW[{N},{K}] M={Mx}: library {t_lib*1e3:8.1f} us ({fl/t_lib/1e9:7.1f} TF)   v1 {t_v1*1e3:8.1f} us ({fl/t_v1/1e9:7.1f} TF)"
-          f"   v2 {t_v2*1e3:8.1f} us ({fl/t_v2/1e9:7.1f} TF)", flush=True)
+          f"   v2 {t_v2*1e3:8.1f} us ({fl/t_v2/1e9:7.1f} TF)   v2-ring3 {t_v3*1e3:8.1f} us ({fl/t_v3/1e9:7.1f} TF)", flush=True)

@@ -441,12 +441,25 @@ void wgrad2_accum(const Tensor& dy, const Tensor& x, Tensor ws) {
                    x.stride(0), 0, cur_stream());
 }
 
+Tensor colsum(const Tensor& x) {
+  TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.stride(1) == 1 &&
+                  (x.scalar_type() == at::kBFloat16 || x.scalar_type() == at::kFloat),
+              "colsum: bf16/fp32 [M, N] with unit inner stride");
+  TORCH_CHECK(x.size(1) % 8 == 0 && x.stride(0) % 8 == 0 && reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
+              "colsum: 16-byte aligned rows, N % 8 == 0");
+  Tensor out = at::zeros({x.size(1)}, x.options().dtype(at::kFloat));
+  dpa::colsum(x.data_ptr(), out.data_ptr<float>(), x.size(0), (int)x.size(1), x.stride(0), is_bf16(x), cur_stream());
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dpa, m) {
+  m.def("colsum(Tensor x) -> Tensor");
   m.def("wgrad_into(Tensor dy, Tensor x, Tensor(a!) ws, Tensor(b!)? dbias) -> ()");
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
   m.def("wgrad2(Tensor dy, Tensor x) -> Tensor");
+  m.def("wgrad2_set_stages(int s) -> ()");
   m.def("wgrad2_accum(Tensor dy, Tensor x, Tensor(a!) ws) -> ()");
   m.def("layernorm_fwd(Tensor x, Tensor? res, Tensor w, Tensor b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres) -> (Tensor, Tensor, Tensor)");
@@ -471,7 +484,12 @@ TORCH_LIBRARY(dpa, m) {
   m.def("rope_(Tensor(a!) x, Tensor cos_t, Tensor sin_t, int pos0, bool inverse) -> ()");
 }
 
+TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
+  m.impl("wgrad2_set_stages", [](int64_t s) { dpa::wgrad2_set_stages((int)s); });
+}
+
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("colsum", colsum);
   m.impl("wgrad_into", wgrad_into);
   m.impl("ws_to", ws_to);
   m.impl("wgrad2", wgrad2);

@@ -156,11 +156,40 @@ __device__ __forceinline__ void dma_subtile(const bf16_t* g, long long ld, int c
   }
 }
 
-template <bool ACCUM>
-__global__ __launch_bounds__(256, 2) void wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                        float* __restrict__ slabs, int M, int N, int K, long long ldy,
-                                                        long long ldx, int splits, int mper) {
+// The same sub-tile DMA issued from inline assembly: hipcc treats an LDS-DMA builtin as a write to
+// LDS that any later ds_read may alias and drains it (vmcnt(0)) before the next LDS read, which
+// serialises a multi-stage ring. Issued from asm the transfer is invisible to the compiler's wait
+// insertion and is retired by hand with a counted s_waitcnt before the barrier that publishes
+// the stage. M0 (LDS base of the piece) is written and restored inside the same statement.
+__device__ __forceinline__ void dma_subtile_asm(const bf16_t* g, long long ld, int col_limit, unsigned lds_addr,
+                                                int wave, int lane) {
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int piece = wave * 4 + pc;
+    const int row = piece * 4 + (lane >> 4);
+    int chunk = swz<128>(row, lane & 15);
+    if (chunk * 8 >= col_limit) chunk = 0;
+    const bf16_t* src = g + (long long)row * ld + chunk * 8;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + piece * 1024);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+  }
+}
+
+template <bool ACCUM, int STAGES>
+__global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     float* __restrict__ slabs, int M, int N, int K, long long ldy,
+                                                     long long ldx, int splits, int mper) {
   constexpr int SUB = 64 * 128 * 2;  // 16 KiB
+  constexpr int STAGE = 3 * SUB;     // 48 KiB: dY sub-tile + two X sub-tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int tiles_k = K / kW2K;
@@ -181,16 +210,16 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  char* ya = smem;            // dY sub-tile  [64][128]
-  char* xa = smem + SUB;      // X sub-tiles  [64][128] x 2
-  for (int t = 0; t < ntiles; ++t) {
-    const long long m = m_begin + t * 64;
-    __syncthreads();          // everybody is done reading the previous tile
-    dma_subtile(dy + m * ldy + n0, ldy, N - n0, ya, wave, lane);
-    dma_subtile(x + m * ldx + k0, ldx, K - k0, xa, wave, lane);
-    dma_subtile(x + m * ldx + k0 + 128, ldx, K - k0 - 128, xa + SUB, wave, lane);
-    __syncthreads();          // waits for this wave's DMA (vmcnt) and for everybody else's
-    const char* xb = xa + (wave >> 1) * SUB;
+  auto issue = [&](int t, int stage) {
+    const long long m = m_begin + (long long)t * 64;
+    char* base = smem + stage * STAGE;
+    dma_subtile(dy + m * ldy + n0, ldy, N - n0, base, wave, lane);
+    dma_subtile(x + m * ldx + k0, ldx, K - k0, base + SUB, wave, lane);
+    dma_subtile(x + m * ldx + k0 + 128, ldx, K - k0 - 128, base + 2 * SUB, wave, lane);
+  };
+  auto compute = [&](int stage) {
+    const char* ya = smem + stage * STAGE;
+    const char* xb = ya + SUB + (wave >> 1) * SUB;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bfrag a[4], b[2];
@@ -202,6 +231,48 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const bf16_t* __restrict
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+  };
+
+  if (STAGES == 3) {
+    // Three-stage ring, one workgroup per CU: the DMAs of tiles t+1 and t+2 stay in flight during
+    // the MFMAs of tile t. Per tile: wait until all but this wave's newest 12 DMAs (tile t+1)
+    // have landed, one barrier (publishes tile t, and proves every wave is done with tile t-1
+    // whose stage is refilled next), issue tile t+2, compute tile t.
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    auto issue_asm = [&](int t, int stage) {
+      const long long m = m_begin + (long long)t * 64;
+      const unsigned base = lds0 + stage * STAGE;
+      dma_subtile_asm(dy + m * ldy + n0, ldy, N - n0, base, wave, lane);
+      dma_subtile_asm(x + m * ldx + k0, ldx, K - k0, base + SUB, wave, lane);
+      dma_subtile_asm(x + m * ldx + k0 + 128, ldx, K - k0 - 128, base + 2 * SUB, wave, lane);
+    };
+    if (ntiles > 0) issue_asm(0, 0);
+    if (ntiles > 1) issue_asm(1, 1);
+    int stage = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < ntiles) issue_asm(t + 2, stage == 0 ? 2 : stage - 1);
+      compute(stage);
+      stage = (stage == 2) ? 0 : stage + 1;
+    }
+  } else if (STAGES == 1) {
+    for (int t = 0; t < ntiles; ++t) {
+      __syncthreads();          // everybody is done reading the previous tile
+      issue(t, 0);
+      __syncthreads();          // waits for this wave's DMA (vmcnt) and for everybody else's
+      compute(0);
+    }
+  } else {
+    // Double-buffered: the DMA of tile t+1 is in flight during the MFMAs of tile t; one barrier
+    // per tile (it drains this wave's DMA, then orders it against everybody's reads).
+    if (ntiles > 0) issue(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+      __syncthreads();          // tile t has landed; all waves finished computing tile t-1
+      if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+      compute(t & 1);
     }
   }
 
@@ -277,9 +348,11 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 
 bool wgrad2_ok(int M, int N, int K) { return M % 64 == 0 && M >= 64 && N % 8 == 0 && K % kW2K == 0; }
 
+int g_wgrad2_stages = 1;   // tuning knob (benchmarks): 1 = single LDS buffer, 2 = double-buffered, 3 = ring
+
 int wgrad2_splits(int M, int N, int K) {
   const int tiles = ((N + kW2N - 1) / kW2N) * (K / kW2K);
-  int s = 512 / tiles;                 // two workgroups per CU in a single round
+  int s = (g_wgrad2_stages == 1 ? 512 : 256) / tiles;   // one round of the workgroups that fit per CU
   const int max_s = M / 256;           // at least 4 LDS tiles per workgroup
   if (s > max_s) s = max_s;
   if (s > 64) s = 64;
@@ -289,19 +362,33 @@ int wgrad2_splits(int M, int N, int K) {
 
 // splits > 0: writes `splits` slabs (ws holds splits*N*K floats). splits == 0: a single pass
 // over all tokens that ADDS into ws[N*K] (accumulation across calls, e.g. lm_head row chunks).
+void wgrad2_set_stages(int s) { g_wgrad2_stages = s; }
+
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
                  int splits, hipStream_t st) {
   if (M == 0) return;
   const int sp = splits > 0 ? splits : 1;
   int mper = (M / 64 + sp - 1) / sp * 64;
   const dim3 grid(((N + kW2N - 1) / kW2N) * (K / kW2K) * sp), block(256);
-  const size_t lds = 3 * 64 * 128 * 2;  // 48 KiB
-  if (splits > 0)
-    hipLaunchKernelGGL((wgrad2_kernel<false>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
-                       ldy, ldx, sp, mper);
-  else
-    hipLaunchKernelGGL((wgrad2_kernel<true>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
-                       ldy, ldx, 1, mper);
+  const int stages = g_wgrad2_stages;
+  const size_t lds = (size_t)stages * 3 * 64 * 128 * 2;  // 48 KiB per stage
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    attr = true;
+  }
+#define DPA_W2(ACC, ST)                                                                                        \
+  hipLaunchKernelGGL((wgrad2_kernel<ACC, ST>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, \
+                     K, ldy, ldx, sp, mper)
+  if (splits > 0) {
+    if (stages == 3) DPA_W2(false, 3); else if (stages == 2) DPA_W2(false, 2); else DPA_W2(false, 1);
+  } else {
+    if (stages == 3) DPA_W2(true, 3); else if (stages == 2) DPA_W2(true, 2); else DPA_W2(true, 1);
+  }
+#undef DPA_W2
 }
 
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,

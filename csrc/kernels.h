@@ -76,10 +76,15 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 // splits == 0: one pass that adds into ws[N*K].
 bool wgrad2_ok(int M, int N, int K);
 int wgrad2_splits(int M, int N, int K);
+void wgrad2_set_stages(int s);
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
                  int splits, hipStream_t st);
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
                   hipStream_t st);
+
+// ---- Column sums (bias gradients) ----------------------------------------------------------
+// out[N] (fp32, caller-zeroed) += column sums of x[M, N] (row stride ld elements, N % 8 == 0).
+void colsum(const void* x, float* out, long long M, int N, long long ld, bool is_bf16, hipStream_t st);
 
 // ---- RoPE -------------------------------------------------------------------------------
 // In-place interleaved-pair rotation of `nheads` heads of size hs at x + t*ts (+ b*bs), using

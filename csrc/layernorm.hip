@@ -12,14 +12,25 @@
 
 namespace dpa {
 
-template <typename T, int NCH>
+// Sum over the LPR lanes (32 or 64) that share a row.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LPR lanes own one row (LPR = 32: two rows per wave, used when the row has an odd multiple of
+// 32 sixteen-byte chunks, e.g. C = 768 -> 96 chunks = 3 per lane with no idle lanes).
+template <typename T, int NCH, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                      const T* __restrict__ w, const T* __restrict__ b,
                                                      T* __restrict__ y, T* __restrict__ sum_out,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int rows, int C, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int RPW = 64 / LPR;                       // rows per wave
+  const int lane = threadIdx.x & (LPR - 1);
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
   if (row >= rows) return;
   const int nchunk = C >> 3;
   const T* xr = x + (size_t)row * C;
@@ -27,7 +38,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LPR;
     if (c < nchunk) {
       load8(xr + c * 8, v[i]);
       if (res != nullptr) {
@@ -44,11 +55,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       for (int j = 0; j < 8; ++j) s += v[i][j];
     }
   }
-  const float mean = wave_sum(s) / C;
+  const float mean = row_sum<LPR>(s) / C;
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LPR;
     if (c < nchunk) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -57,14 +68,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(ss) / C + eps);
+  const float rstd = rsqrtf(row_sum<LPR>(ss) / C + eps);
   if (lane == 0) {
     if (mean_out) mean_out[row] = mean;
     if (rstd_out) rstd_out[row] = rstd;
   }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LPR;
     if (c < nchunk) {
       float wv[8], bv[8], o[8];
       load8(w + c * 8, wv);
@@ -79,19 +90,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Backward. Each wave walks rows with a grid stride and keeps its dgamma/dbeta partial sums in
 // registers; the four waves of a block are combined through LDS and written as one partial
 // row per block. A second kernel folds the partial rows.
-template <typename T, int NCH>
+template <typename T, int NCH, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ part_dw,
                                                      float* __restrict__ part_db, int rows, int C) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & (LPR - 1), wid = threadIdx.x >> 6, sub = (threadIdx.x & 63) / LPR;
   const int nchunk = C >> 3;
   float aw[NCH][8], ab[NCH][8], wv[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LPR;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       aw[i][j] = 0.f;
@@ -100,13 +112,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     if (c < nchunk) load8(w + c * 8, wv[i]);
   }
-  for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+  for (int row = (blockIdx.x * 4 + wid) * RPW + sub; row < rows; row += gridDim.x * 4 * RPW) {
     const float mu = mean[row], rs = rstd[row];
     float g[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
+      const int c = lane + i * LPR;
       if (c < nchunk) {
         float d[8], xv[8];
         load8(dy + (size_t)row * C + c * 8, d);
@@ -122,11 +134,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
+    s1 = row_sum<LPR>(s1) / C;
+    s2 = row_sum<LPR>(s2) / C;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
+      const int c = lane + i * LPR;
       if (c < nchunk) {
         float o[8];
 #pragma unroll
@@ -141,24 +153,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  // Combine the 4 waves: lds[wave][C] for dw, then the same for db.
-  float* lw = lds;            // 4*C
-  float* lb = lds + 4 * C;    // 4*C
+  // Combine the 4*RPW row groups of the block: lds[group][C] for dw, then the same for db.
+  constexpr int G = 4 * RPW;
+  float* lw = lds;            // G*C
+  float* lb = lds + G * C;    // G*C
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LPR;
     if (c < nchunk) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        lw[wid * C + c * 8 + j] = aw[i][j];
-        lb[wid * C + c * 8 + j] = ab[i][j];
+        lw[(wid * RPW + sub) * C + c * 8 + j] = aw[i][j];
+        lb[(wid * RPW + sub) * C + c * 8 + j] = ab[i][j];
       }
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    part_dw[(size_t)blockIdx.x * C + c] = lw[c] + lw[C + c] + lw[2 * C + c] + lw[3 * C + c];
-    part_db[(size_t)blockIdx.x * C + c] = lb[c] + lb[C + c] + lb[2 * C + c] + lb[3 * C + c];
+    float tw = 0.f, tb = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      tw += lw[g * C + c];
+      tb += lb[g * C + c];
+    }
+    part_dw[(size_t)blockIdx.x * C + c] = tw;
+    part_db[(size_t)blockIdx.x * C + c] = tb;
   }
 }
 
@@ -214,45 +233,80 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   }
 }
 
-static int pick_nch(int C) {
-  const int need = (C / 8 + 63) / 64;
-  int n = 1;
-  while (n < need) n <<= 1;
-  return n;
+// Lanes per row and chunks per lane for a row of C elements (C % 8 == 0).
+static void pick_shape(int C, int& lpr, int& nch) {
+  const int nchunk = C / 8;
+  lpr = (nchunk % 32 == 0 && (nchunk % 64 != 0 || nchunk < 64) && nchunk <= 32 * 8) ? 32 : 64;
+  const int need = (nchunk + lpr - 1) / lpr;
+  nch = 1;
+  while (nch < need) nch <<= 1;
+  if (lpr == 32 && nch != need) {       // keep the 32-lane form only when it divides evenly (1,2,3,4,6,8 -> pad to pow2 otherwise)
+    if (need == 3) nch = 3;
+    else if (need == 6) nch = 6;
+  }
 }
 
 template <typename T>
 static void ln_fwd_launch(const T* x, const T* res, const T* w, const T* b, T* y, T* sum_out, float* mean,
                           float* rstd, int rows, int C, float eps, hipStream_t st) {
-  const dim3 grid((rows + 3) / 4), block(256);
-  switch (pick_nch(C)) {
-#define DPA_CASE(N)                                                                                   \
-  case N:                                                                                             \
-    hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, x, res, w, b, y, sum_out, mean, rstd, \
-                       rows, C, eps);                                                                 \
-    break;
-    DPA_CASE(1) DPA_CASE(2) DPA_CASE(4) DPA_CASE(8) DPA_CASE(16)
-#undef DPA_CASE
+  int lpr, nch;
+  pick_shape(C, lpr, nch);
+  const int rpb = 4 * (64 / lpr);
+  const dim3 grid((rows + rpb - 1) / rpb), block(256);
+#define DPA_CASE(N, L)                                                                                     \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, N, L>), grid, block, 0, st, x, res, w, b, y, sum_out, mean, rstd, rows, C, eps)
+  if (lpr == 32) {
+    switch (nch) {
+      case 1: DPA_CASE(1, 32); break;
+      case 2: DPA_CASE(2, 32); break;
+      case 3: DPA_CASE(3, 32); break;
+      case 4: DPA_CASE(4, 32); break;
+      case 6: DPA_CASE(6, 32); break;
+      default: DPA_CASE(8, 32); break;
+    }
+  } else {
+    switch (nch) {
+      case 1: DPA_CASE(1, 64); break;
+      case 2: DPA_CASE(2, 64); break;
+      case 4: DPA_CASE(4, 64); break;
+      case 8: DPA_CASE(8, 64); break;
+      default: DPA_CASE(16, 64); break;
+    }
   }
+#undef DPA_CASE
 }
 
 template <typename T>
 static void ln_bwd_launch(const T* dy, const T* x, const T* w, const float* mean, const float* rstd,
                           const T* dres, T* dx, T* dw, T* db, float* scratch, int nparts, int rows, int C,
                           int accumulate, hipStream_t st) {
+  int lpr, nch;
+  pick_shape(C, lpr, nch);
   const dim3 grid(nparts), block(256);
-  const size_t lds = (size_t)8 * C * sizeof(float);
+  const size_t lds = (size_t)2 * 4 * (64 / lpr) * C * sizeof(float);
   float* pw = scratch;
   float* pb = scratch + (size_t)nparts * C;
-  switch (pick_nch(C)) {
-#define DPA_CASE(N)                                                                                     \
-  case N:                                                                                               \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, lds, st, dy, x, w, mean, rstd, dres, dx, pw, pb, \
-                       rows, C);                                                                        \
-    break;
-    DPA_CASE(1) DPA_CASE(2) DPA_CASE(4) DPA_CASE(8) DPA_CASE(16)
-#undef DPA_CASE
+#define DPA_CASE(N, L)                                                                                        \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, N, L>), grid, block, lds, st, dy, x, w, mean, rstd, dres, dx, pw, pb, rows, C)
+  if (lpr == 32) {
+    switch (nch) {
+      case 1: DPA_CASE(1, 32); break;
+      case 2: DPA_CASE(2, 32); break;
+      case 3: DPA_CASE(3, 32); break;
+      case 4: DPA_CASE(4, 32); break;
+      case 6: DPA_CASE(6, 32); break;
+      default: DPA_CASE(8, 32); break;
+    }
+  } else {
+    switch (nch) {
+      case 1: DPA_CASE(1, 64); break;
+      case 2: DPA_CASE(2, 64); break;
+      case 4: DPA_CASE(4, 64); break;
+      case 8: DPA_CASE(8, 64); break;
+      default: DPA_CASE(16, 64); break;
+    }
   }
+#undef DPA_CASE
   hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3((C + 63) / 64), dim3(1024), 0, st, pw, pb, dw, db, nparts,
                      C, accumulate);
 }
@@ -260,7 +314,7 @@ static void ln_bwd_launch(const T* dy, const T* x, const T* w, const float* mean
 int layernorm_max_cols() { return 16 * 64 * 8; }  // 8192; LDS in the backward: 8*C*4 B <= 160 KiB -> C <= 5120
 
 int layernorm_bwd_parts(int rows) {
-  int n = (rows + 3) / 4;
+  int n = (rows + 7) / 8;
   return n < 1 ? 1 : (n > 512 ? 512 : n);  // 2 workgroups (8 waves) per CU keep HBM busy
 }
 

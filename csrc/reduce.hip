@@ -1,0 +1,55 @@
+// Column sums of a row-major [M, N] activation (bias gradients): out[n] += sum_m x[m, n].
+// Every thread owns 8 adjacent columns (one 16-byte load per row), a workgroup of 4 waves
+// covers 512 columns x a strip of rows, the waves are combined through LDS and one float
+// atomic per column and workgroup lands in the fp32 output (zeroed by the caller).
+//
+// Replaces the `dy.sum(0)` reductions that `nn.Linear`'s backward issues for its bias
+// (reference: single-gpu/model.py:112-114, biases of c_attn / c_proj).
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long long M,
+                                                     int N, long long ld, int rows_per_block) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < N) {
+    for (long long r = r0 + wave; r < r1; r += 4) {
+      float v[8];
+      load8(x + r * ld + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int col = blockIdx.x * 512 + c;
+    if (col < N) atomicAdd(out + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
+void colsum(const void* x, float* out, long long M, int N, long long ld, bool is_bf16, hipStream_t st) {
+  if (M == 0 || N == 0) return;
+  const int cblocks = (N + 511) / 512;
+  long long strips = 2048 / cblocks;
+  if (strips < 1) strips = 1;
+  long long rpb = (M + strips - 1) / strips;
+  if (rpb < 16) rpb = 16;
+  strips = (M + rpb - 1) / rpb;
+  const dim3 grid(cblocks, (unsigned)strips), block(256);
+  if (is_bf16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, out, M, N, ld, (int)rpb);
+  else
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)x, out, M, N, ld, (int)rpb);
+}
+
+}  // namespace dpa

@@ -32,12 +32,20 @@ def wgrad2_supported(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
 
 
+def bias_grad(dy2: torch.Tensor) -> torch.Tensor:
+    """Column sums of dy2 [M, N] in its own dtype (fp32 accumulation on the GPU kernel)."""
+    if (dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float32) and dy2.stride(1) == 1
+            and dy2.shape[1] % 8 == 0 and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0):
+        return ops().colsum(dy2).to(dy2.dtype)
+    return dy2.sum(0)
+
+
 def weight_grad(dy2: torch.Tensor, x2: torch.Tensor, want_bias: bool, version: int = 0):
     """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16."""
     N, K = dy2.shape[1], x2.shape[1]
     if version != 1 and wgrad2_supported(dy2, x2):
         dw = ops().wgrad2(dy2, x2)
-        return dw, (dy2.sum(0) if want_bias else None)
+        return dw, (bias_grad(dy2) if want_bias else None)
     ws = torch.zeros(N, K, dtype=torch.float32, device=dy2.device)
     bws = torch.zeros(N, dtype=torch.float32, device=dy2.device) if want_bias else None
     ops().wgrad_into(dy2, x2, ws, bws)
@@ -68,9 +76,9 @@ class _LinearFn(torch.autograd.Function):
             else:
                 dw = torch.mm(dy2.t(), x2)
                 if need_b:
-                    db = dy2.sum(0)
+                    db = bias_grad(dy2)
         elif need_b:
-            db = dy2.sum(0)
+            db = bias_grad(dy2)
         return dx, dw, db
 
 

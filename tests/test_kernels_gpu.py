@@ -344,3 +344,14 @@ def test_wgrad2_gemm(M, N, K):
     ws = torch.ones(N, K, device=DEV)
     hip().wgrad2_accum(dy, x, ws)
     assert rel_err(ws, want + 1.0) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,dtype", [(32768, 2304, torch.bfloat16), (1000, 768, torch.bfloat16), (77, 520, torch.float32)])
+def test_colsum(M, N, dtype):
+    from distributed_pytorch_amd._ext import ops as hip
+    torch.manual_seed(13)
+    x = torch.randn(M, N, device=DEV).to(dtype)
+    got = hip().colsum(x)
+    assert rel_err(got, x.float().sum(0)) < 1e-4
+    view = x[:, : N // 2 // 8 * 8]          # strided rows
+    assert rel_err(hip().colsum(view), view.float().sum(0)) < 1e-4
