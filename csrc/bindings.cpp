@@ -430,6 +430,20 @@ Tensor wgrad2(const Tensor& dy, const Tensor& x) {
   return dw;
 }
 
+// The per-split fp32 slabs [splits, N, K] of dy^T x (the caller folds them with ws_to, possibly
+// straight into a flat gradient buffer with accumulate = true).
+Tensor wgrad2_slabs(const Tensor& dy, const Tensor& x) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1);
+  TORCH_CHECK(x.size(0) == M && dpa::wgrad2_ok((int)M, (int)N, (int)K), "wgrad2: unsupported shape ", M, "x", N, "x", K);
+  const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
+  Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
+  dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                   x.stride(0), splits, cur_stream());
+  return slabs;
+}
+
 // ws[N, K] (fp32) += dy^T x in one pass over the tokens (accumulation across row chunks).
 void wgrad2_accum(const Tensor& dy, const Tensor& x, Tensor ws) {
   check_rows2d(dy, "dy");
@@ -460,6 +474,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
   m.def("wgrad2(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_set_stages(int s) -> ()");
+  m.def("wgrad2_slabs(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_accum(Tensor dy, Tensor x, Tensor(a!) ws) -> ()");
   m.def("layernorm_fwd(Tensor x, Tensor? res, Tensor w, Tensor b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres) -> (Tensor, Tensor, Tensor)");
@@ -493,6 +508,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("wgrad_into", wgrad_into);
   m.impl("ws_to", ws_to);
   m.impl("wgrad2", wgrad2);
+  m.impl("wgrad2_slabs", wgrad2_slabs);
   m.impl("wgrad2_accum", wgrad2_accum);
   m.impl("layernorm_fwd", layernorm_fwd);
   m.impl("layernorm_bwd", layernorm_bwd);

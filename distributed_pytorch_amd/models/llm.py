@@ -91,7 +91,7 @@ class GQA(nn.Module):
         B, T, C = x.shape
         nh, nkv, hs = self.config.n_head, self.config.n_kv_heads, self.head_size
         p_drop = self.config.dropout if self.training else 0.0
-        qkv = ops.linear(x, self.c_attn.weight, self.c_attn.bias)
+        qkv = ops.linear(x, self.c_attn.weight, self.c_attn.bias, sole_use=True)
         if rope is not None:
             # rotate the q and k heads (contiguous leading part of the fused projection)
             cos_t, sin_t, pos0 = rope
@@ -109,7 +109,7 @@ class GQA(nn.Module):
             y = ops.causal_attention(q, k, v, dropout_p=p_drop)
             new_cache = (k.transpose(1, 2), v.transpose(1, 2))  # reference cache shape (B, nkv, T, hs)
         y = y.reshape(B, T, C)
-        y = _drop(ops.linear(y, self.c_proj.weight, self.c_proj.bias), self.config.dropout, self.training)
+        y = _drop(ops.linear(y, self.c_proj.weight, self.c_proj.bias, sole_use=True), self.config.dropout, self.training)
         return y, new_cache
 
     def _want_cache(self) -> bool:
@@ -274,9 +274,9 @@ class MLP(nn.Module):
         self.p_drop = config.dropout
 
     def forward(self, x):
-        h = ops.linear(x, self.c_fc.weight)
+        h = ops.linear(x, self.c_fc.weight, sole_use=True)
         h = ops.swiglu(h) if self.non_linearity == "swiglu" else self._act(h)
-        return _drop(ops.linear(h, self.c_proj.weight), self.p_drop, self.training)
+        return _drop(ops.linear(h, self.c_proj.weight, sole_use=True), self.p_drop, self.training)
 
 
 class Expert(nn.Module):

@@ -54,11 +54,24 @@ def weight_grad(dy2: torch.Tensor, x2: torch.Tensor, want_bias: bool, version: i
     return dw, (bws.to(dy2.dtype) if want_bias else None)
 
 
+def _direct_target(w_param, dy2, x2):
+    """The flat-buffer gradient view of ``w_param`` if the engine that owns it asked for direct
+    accumulation (``_dpa_direct``) and the kernel can write it, else None."""
+    if not getattr(w_param, "_dpa_direct", False):
+        return None
+    g = w_param.grad
+    if g is None or g.dtype not in (torch.bfloat16, torch.float32) or not g.is_contiguous() \
+            or g.data_ptr() % 16 != 0 or g.numel() % 8 != 0:
+        return None
+    return g if wgrad2_supported(dy2, x2) else None
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, sole_use):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.w_param = w if sole_use else None
         return F.linear(x, w, b)
 
     @staticmethod
@@ -70,7 +83,18 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, w).view(x.shape)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        target = None
+        if ctx.w_param is not None and ctx.needs_input_grad[1]:
+            target = _direct_target(ctx.w_param, dy2, x2)
+        if target is not None:
+            # Fold the split slabs straight into the engine's flat gradient buffer (one pass instead
+            # of convert + autograd's accumulate). Returning None for dw still runs the parameter's
+            # AccumulateGrad node, so post-accumulate hooks (bucket / unit accounting of the
+            # engines) fire exactly as they do for an autograd-accumulated gradient.
+            ops().ws_to(ops().wgrad2_slabs(dy2, x2), target, True)
+            if need_b:
+                db = bias_grad(dy2)
+        elif ctx.needs_input_grad[1]:
             if wgrad2_supported(dy2, x2) or wgrad_supported(dy2, x2):
                 dw, db = weight_grad(dy2, x2, need_b)
             else:
@@ -79,11 +103,14 @@ class _LinearFn(torch.autograd.Function):
                     db = bias_grad(dy2)
         elif need_b:
             db = bias_grad(dy2)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, sole_use: bool = False) -> torch.Tensor:
+    """``x @ w.T + b``. ``sole_use=True`` promises that this call is the only consumer of ``w`` in
+    the forward pass, which allows its gradient to be accumulated straight into the owning
+    engine's flat gradient buffer (see ``_direct_target``)."""
     if use_hip(x, w) and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and torch.is_grad_enabled() \
             and (x.requires_grad or w.requires_grad):
-        return _LinearFn.apply(x, w, b)
+        return _LinearFn.apply(x, w, b, sole_use)
     return F.linear(x, w, b)

@@ -110,6 +110,18 @@ class Engine(nn.Module):
         self.optims = [FlatAdamW(g, *self._opt_range(g), betas=self.betas, eps=self.eps) for g in self.groups]
         for g in self.groups:
             g.drop_init()
+        self._enable_direct_grads()
+
+    def _enable_direct_grads(self):
+        """Let the weight-gradient kernel accumulate straight into the flat gradient buffers
+        (see ``ops/linear.py``). Post-accumulate hooks still fire for such parameters."""
+        import os
+        if self.device.type != "cuda" or os.environ.get("DPA_DIRECT_GRAD", "1") != "1":
+            return
+        for g in self.groups:
+            for s in g.slots:
+                if s.param.dim() == 2:
+                    s.param._dpa_direct = True
 
     def _opt_range(self, g: FlatGroup):
         return 0, g.numel

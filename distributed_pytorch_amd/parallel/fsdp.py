@@ -135,6 +135,7 @@ class FSDPEngine(Engine):
         for ui, u in enumerate(self.units):
             for s in u.slots:
                 s.param.register_post_accumulate_grad_hook(self._make_grad_hook(ui))
+        self._enable_direct_grads()
         for u in self.block_units:
             u.release_params()
 
