@@ -51,7 +51,11 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
-    device = torch.device(f"cuda:{local_rank}") if use_cuda else torch.device("cpu")
+    # DPA_BACKEND=gloo lets several ranks share one GPU (rehearsal of the GPU code paths of the
+    # engines on a single-GPU box; RCCL itself refuses two ranks on one device).
+    backend = backend or os.environ.get("DPA_BACKEND") or None
+    ndev = torch.cuda.device_count() if use_cuda else 0
+    device = torch.device(f"cuda:{local_rank % ndev}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
     if world == 1:

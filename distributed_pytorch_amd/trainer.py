@@ -74,9 +74,9 @@ def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
     if mode in ("zero1", "zero2"):
         from .parallel.zero import ZeroEngine
         return ZeroEngine(model, stage=int(mode[-1]), **kw)
-    if mode == "fsdp":
+    if mode in ("fsdp", "fsdp_keep"):
         from .parallel.fsdp import FSDPEngine
-        return FSDPEngine(model, **kw)
+        return FSDPEngine(model, reshard_after_forward=(mode == "fsdp"), **kw)
     raise ValueError(f"unknown parallel mode {mode!r}")
 
 
