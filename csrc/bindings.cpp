@@ -466,9 +466,108 @@ Tensor colsum(const Tensor& x) {
   return out;
 }
 
+// ---------------------------------------------------------------------------------------
+// Grouped GEMM over 128-row blocks: c = a * W_g^T (w_is_kn = false, W_g [w_rows = N, w_cols = K]) or
+// c = a * W_g (w_is_kn = true, W_g [w_rows = K, w_cols = N]). Rows of skipped blocks are left
+// uninitialised.
+Tensor grouped_gemm(const Tensor& a, const Tensor& w_ptrs, int64_t w_rows, int64_t w_cols, bool w_is_kn,
+                    const Tensor& block_group) {
+  check_rows2d(a, "a");
+  const int64_t rows = a.size(0), K = a.size(1);
+  const int64_t N = w_is_kn ? w_cols : w_rows;
+  TORCH_CHECK((w_is_kn ? w_rows : w_cols) == K, "grouped_gemm: contraction mismatch");
+  TORCH_CHECK(K % 64 == 0 && N % 8 == 0 && w_cols % 8 == 0, "grouped_gemm: K % 64 == 0 and N % 8 == 0 required");
+  TORCH_CHECK(rows % 128 == 0, "grouped_gemm: rows must be padded to a multiple of 128");
+  TORCH_CHECK(w_ptrs.is_cuda() && w_ptrs.scalar_type() == at::kLong && w_ptrs.is_contiguous(), "w_ptrs: int64 cuda");
+  TORCH_CHECK(block_group.is_cuda() && block_group.scalar_type() == at::kInt && block_group.is_contiguous() &&
+                  block_group.numel() == rows / 128,
+              "block_group: int32 [rows / 128]");
+  Tensor c = at::empty({rows, N}, a.options());
+  dpa::gemm_grouped(a.data_ptr(), a.stride(0), (const long long*)w_ptrs.data_ptr<int64_t>(),
+                    w_cols, w_is_kn, c.data_ptr(), N, block_group.data_ptr<int>(), (int)w_ptrs.numel(), (int)rows,
+                    (int)N, (int)K, cur_stream());
+  return c;
+}
+
+// fp32 [G, N, K] = per-segment dy^T x.
+Tensor grouped_wgrad(const Tensor& dy, const Tensor& x, const Tensor& seg_start, const Tensor& seg_rows) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1), G = seg_start.numel();
+  TORCH_CHECK(x.size(0) == M && K % 128 == 0 && N % 8 == 0, "grouped_wgrad: unsupported shape");
+  TORCH_CHECK(seg_start.is_cuda() && seg_start.scalar_type() == at::kLong && seg_start.is_contiguous() &&
+                  seg_rows.is_cuda() && seg_rows.scalar_type() == at::kLong && seg_rows.is_contiguous() &&
+                  seg_rows.numel() == G,
+              "grouped_wgrad: segment tables are int64 cuda [G]");
+  Tensor out = at::zeros({G, N, K}, dy.options().dtype(at::kFloat));
+  dpa::gemm_grouped_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr<float>(),
+                          (const long long*)seg_start.data_ptr<int64_t>(), (const long long*)seg_rows.data_ptr<int64_t>(),
+                          (int)G, (int)N, (int)K, (int)M, cur_stream());
+  return out;
+}
+
+void check_pairs(const Tensor& row_of_pair) {
+  TORCH_CHECK(row_of_pair.is_cuda() && row_of_pair.scalar_type() == at::kLong && row_of_pair.is_contiguous(),
+              "row_of_pair: int64 cuda");
+}
+
+// dst[row_of_pair[j]] = src[j / k]; other rows zero.
+Tensor moe_scatter_rows(const Tensor& src, const Tensor& row_of_pair, int64_t k, int64_t rows_out) {
+  check_rows2d(src, "src");
+  check_pairs(row_of_pair);
+  TORCH_CHECK(src.is_contiguous() && src.size(1) % 8 == 0 && row_of_pair.numel() == src.size(0) * k);
+  Tensor dst = at::zeros({rows_out, src.size(1)}, src.options());
+  dpa::moe_scatter_rows(src.data_ptr(), (const long long*)row_of_pair.data_ptr<int64_t>(), dst.data_ptr(),
+                        row_of_pair.numel(), (int)k, (int)src.size(1), cur_stream());
+  return dst;
+}
+
+// out[t] = sum_s gates[t, s] * y[row_of_pair[t * k + s]]  (gates absent: plain sum).
+Tensor moe_gather_combine(const Tensor& y, const Tensor& row_of_pair, const std::optional<Tensor>& gates, int64_t k) {
+  check_rows2d(y, "y");
+  check_pairs(row_of_pair);
+  TORCH_CHECK(y.is_contiguous() && y.size(1) % 8 == 0 && row_of_pair.numel() % k == 0);
+  const int64_t ntok = row_of_pair.numel() / k;
+  const void* gp = nullptr;
+  if (gates.has_value()) {
+    TORCH_CHECK(gates->is_cuda() && gates->scalar_type() == at::kBFloat16 && gates->is_contiguous() &&
+                    gates->numel() == ntok * k,
+                "gates: bf16 [tokens, k]");
+    gp = gates->data_ptr();
+  }
+  Tensor out = at::empty({ntok, y.size(1)}, y.options());
+  dpa::moe_gather_combine(y.data_ptr(), (const long long*)row_of_pair.data_ptr<int64_t>(), gp, out.data_ptr(), ntok,
+                          (int)k, (int)y.size(1), cur_stream());
+  return out;
+}
+
+std::tuple<Tensor, Tensor> moe_combine_bwd(const Tensor& dout, const Tensor& y, const Tensor& row_of_pair,
+                                           const Tensor& gates) {
+  check_rows2d(dout, "dout");
+  check_rows2d(y, "y");
+  check_pairs(row_of_pair);
+  const int64_t ntok = dout.size(0), C = dout.size(1), npairs = row_of_pair.numel();
+  TORCH_CHECK(dout.is_contiguous() && y.is_contiguous() && y.size(1) == C && C % 8 == 0 && ntok > 0 &&
+              npairs % ntok == 0);
+  TORCH_CHECK(gates.is_cuda() && gates.scalar_type() == at::kBFloat16 && gates.is_contiguous() &&
+                  gates.numel() == npairs,
+              "gates: bf16 [tokens, k]");
+  Tensor dy = at::zeros_like(y);
+  Tensor dgate = at::empty({ntok, npairs / ntok}, dout.options().dtype(at::kFloat));
+  dpa::moe_combine_bwd(dout.data_ptr(), y.data_ptr(), (const long long*)row_of_pair.data_ptr<int64_t>(),
+                       gates.data_ptr(), dy.data_ptr(), dgate.data_ptr<float>(), npairs, (int)(npairs / ntok), (int)C,
+                       cur_stream());
+  return {dy, dgate};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dpa, m) {
+  m.def("grouped_gemm(Tensor a, Tensor w_ptrs, int w_rows, int w_cols, bool w_is_kn, Tensor block_group) -> Tensor");
+  m.def("grouped_wgrad(Tensor dy, Tensor x, Tensor seg_start, Tensor seg_rows) -> Tensor");
+  m.def("moe_scatter_rows(Tensor src, Tensor row_of_pair, int k, int rows_out) -> Tensor");
+  m.def("moe_gather_combine(Tensor y, Tensor row_of_pair, Tensor? gates, int k) -> Tensor");
+  m.def("moe_combine_bwd(Tensor dout, Tensor y, Tensor row_of_pair, Tensor gates) -> (Tensor, Tensor)");
   m.def("colsum(Tensor x) -> Tensor");
   m.def("wgrad_into(Tensor dy, Tensor x, Tensor(a!) ws, Tensor(b!)? dbias) -> ()");
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
@@ -504,6 +603,11 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("grouped_gemm", grouped_gemm);
+  m.impl("grouped_wgrad", grouped_wgrad);
+  m.impl("moe_scatter_rows", moe_scatter_rows);
+  m.impl("moe_gather_combine", moe_gather_combine);
+  m.impl("moe_combine_bwd", moe_combine_bwd);
   m.impl("colsum", colsum);
   m.impl("wgrad_into", wgrad_into);
   m.impl("ws_to", ws_to);

@@ -82,6 +82,25 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
                   hipStream_t st);
 
+// ---- Grouped GEMM (MoE experts) ----------------------------------------------------------------
+// c[rows, N] = a[rows, K] * W_g, one weight matrix per 128-row block (block_group[rb]; values outside
+// [0, ngroups) skip the block). w_is_kn = false: W_g is [N, K]; true: W_g is [K, N]. K % 64 == 0,
+// N % 8 == 0, all rows 16-byte aligned.
+void gemm_grouped(const void* a, long long lda, const long long* w_ptrs, long long ldw, bool w_is_kn, void* c,
+                  long long ldc, const int* block_group, int ngroups, int rows, int N, int K, hipStream_t st);
+// out[g, N, K] (fp32, caller-zeroed) += a[seg_g, N]^T * b[seg_g, K]; segment bounds (multiples of 64 rows)
+// are read from device memory. K % 128 == 0, N % 8 == 0.
+void gemm_grouped_wgrad(const void* a, long long lda, const void* b, long long ldb, float* out,
+                        const long long* seg_start, const long long* seg_rows, int ngroups, int N, int K,
+                        int max_rows, hipStream_t st);
+// MoE dispatch / combine row movement (bf16, C % 8 == 0).
+void moe_scatter_rows(const void* src, const long long* row_of_pair, void* dst, long long npairs, int k, int C,
+                      hipStream_t st);
+void moe_gather_combine(const void* y, const long long* row_of_pair, const void* gates, void* out, long long ntok,
+                        int k, int C, hipStream_t st);
+void moe_combine_bwd(const void* dout, const void* y, const long long* row_of_pair, const void* gates, void* dy,
+                     float* dgate, long long npairs, int k, int C, hipStream_t st);
+
 // ---- Column sums (bias gradients) ----------------------------------------------------------
 // out[N] (fp32, caller-zeroed) += column sums of x[M, N] (row stride ld elements, N % 8 == 0).
 void colsum(const void* x, float* out, long long M, int N, long long ld, bool is_bf16, hipStream_t st);

@@ -340,6 +340,14 @@ class MoE(nn.Module):
         scale by the gate and scatter-add back. One host read of the per-expert counts replaces
         the reference's per-expert ``nonzero``."""
         N, k = topk_indices.shape
+        routed = self.experts[self.n_shared:]
+        if not (self.training and self.config.dropout > 0):
+            fcs = [e.expert.c_fc.weight for e in routed]
+            projs = [e.expert.c_proj.weight for e in routed]
+            act = routed[0].expert.non_linearity
+            if ops.grouped_supported(x_flat, fcs, projs, act):
+                # padded expert-sorted layout + grouped MFMA GEMMs: no host sync, no expert loop
+                return ops.grouped_experts(x_flat, topk_indices, topk_gates, fcs, projs, act)
         flat_e = topk_indices.reshape(-1)
         order = torch.argsort(flat_e, stable=True)
         tok = torch.div(order, k, rounding_mode="floor")

@@ -1,0 +1,184 @@
+"""Routed-expert evaluation of a MoE layer without a loop over experts and without a host sync.
+
+The (token, slot) pairs are laid out sorted by expert, every expert's segment padded to a
+multiple of 128 rows inside a buffer whose size is a static bound (``pairs + 127 * experts``
+rounded up). A 128-row block then belongs to exactly one expert, so the grouped MFMA GEMMs of
+``csrc/gemm_grouped.hip`` pick their weight matrix per block from a small device table and the
+whole layer runs with shapes known on the host: no ``.tolist()``, no per-expert launches.
+
+Forward:  scatter rows -> grouped ``X W_fc^T`` -> activation -> grouped ``A W_proj^T`` -> gate-weighted
+gather. Backward mirrors it with the NN form for the input gradients and a segment-aware
+split-M kernel for the weight gradients.
+
+Reference behaviour: the per-expert ``nonzero`` / ``index_add_`` loop of
+single-gpu/model.py:490-502.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .._ext import ops, use_hip
+
+BLOCK = 128
+
+
+def padded_rows(npairs: int, n_experts: int) -> int:
+    """Static row count of the padded expert-sorted buffer."""
+    return (npairs + n_experts * (BLOCK - 1) + BLOCK - 1) // BLOCK * BLOCK
+
+
+def plan(topk_indices: torch.Tensor, n_experts: int):
+    """Device-side layout of the pairs (no host sync).
+
+    -> row_of_pair [N*k] int64 (row of pair ``t*k + s`` in the padded buffer),
+       block_group [rows/128] int32 (expert of each block, ``n_experts`` past the end),
+       seg_start, seg_rows [E] int64 (padded segment of each expert), rows (python int)."""
+    flat_e = topk_indices.reshape(-1)
+    npairs = flat_e.numel()
+    rows = padded_rows(npairs, n_experts)
+    order = torch.argsort(flat_e, stable=True)
+    counts = torch.bincount(flat_e, minlength=n_experts)
+    cstart = torch.cumsum(counts, 0) - counts
+    seg_rows = (counts + (BLOCK - 1)) // BLOCK * BLOCK
+    seg_end = torch.cumsum(seg_rows, 0)
+    seg_start = seg_end - seg_rows
+    e_sorted = flat_e[order]
+    dest = seg_start[e_sorted] + (torch.arange(npairs, device=flat_e.device) - cstart[e_sorted])
+    row_of_pair = torch.empty_like(order)
+    row_of_pair[order] = dest
+    block_first = torch.arange(rows // BLOCK, device=flat_e.device) * BLOCK
+    block_group = torch.searchsorted(seg_end, block_first, right=True).to(torch.int32)
+    return row_of_pair, block_group, seg_start.contiguous(), seg_rows.contiguous(), rows
+
+
+_PTR_TABLES: dict = {}
+
+
+def _ptr_table(ws) -> torch.Tensor:
+    """int64 device tensor of the weights' addresses, cached by the addresses themselves (they only
+    change when an engine re-materialises its parameters)."""
+    key = tuple(w.data_ptr() for w in ws)
+    t = _PTR_TABLES.get(key)
+    if t is None:
+        if len(_PTR_TABLES) > 512:
+            _PTR_TABLES.clear()
+        t = torch.tensor(key, dtype=torch.int64).pin_memory().to(ws[0].device, non_blocking=True)
+        _PTR_TABLES[key] = t
+    return t
+
+
+def _act_fwd(h, act):
+    return ops().swiglu_fwd(h) if act == "swiglu" else ops().gelu_fwd(h)
+
+
+def _act_bwd(da, h, act):
+    return ops().swiglu_bwd(da, h) if act == "swiglu" else ops().gelu_bwd(da, h)
+
+
+def _emit_wgrads(ws32, params, needs):
+    """fp32 [E, N, K] gradients -> per-parameter results: accumulated straight into the engine's
+    flat gradient buffer when the parameter asks for it (``_dpa_direct``), else bf16 tensors."""
+    out = [None] * len(params)
+    lazy = None
+    for i, p in enumerate(params):
+        if not needs[i]:
+            continue
+        g = p.grad if getattr(p, "_dpa_direct", False) else None
+        if g is not None and g.is_contiguous() and g.dtype in (torch.bfloat16, torch.float32) \
+                and g.data_ptr() % 16 == 0 and g.numel() % 8 == 0:
+            ops().ws_to(ws32[i], g, True)
+        else:
+            if lazy is None:
+                lazy = torch.empty(ws32.shape, dtype=torch.bfloat16, device=ws32.device)
+                ops().ws_to(ws32, lazy, False)
+            out[i] = lazy[i]
+    return out
+
+
+class _GroupedExpertsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_flat, gates, topk_indices, act, n_experts, *weights):
+        E = n_experts
+        fc, proj = weights[:E], weights[E:]
+        k = topk_indices.shape[1]
+        row_of_pair, block_group, seg_start, seg_rows, rows = plan(topk_indices, E)
+        fc_ptrs, proj_ptrs = _ptr_table(fc), _ptr_table(proj)
+        xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows)
+        h = ops().grouped_gemm(xs, fc_ptrs, fc[0].shape[0], fc[0].shape[1], False, block_group)
+        a = _act_fwd(h, act)
+        y = ops().grouped_gemm(a, proj_ptrs, proj[0].shape[0], proj[0].shape[1], False, block_group)
+        gates_c = gates.contiguous()
+        out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
+        ctx.save_for_backward(xs, h, y, gates_c, row_of_pair, block_group, seg_start, seg_rows)
+        ctx.params = weights
+        ctx.act = act
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, h, y, gates, row_of_pair, block_group, seg_start, seg_rows = ctx.saved_tensors
+        weights = ctx.params
+        E = len(weights) // 2
+        fc, proj = weights[:E], weights[E:]
+        # Addresses are looked up again: a sharding engine may have re-materialised the weights.
+        fc_ptrs, proj_ptrs = _ptr_table(fc), _ptr_table(proj)
+        needs = ctx.needs_input_grad[5:]
+        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        a = _act_fwd(h, ctx.act)
+        g_proj = [None] * E
+        if any(needs[E:]):
+            g_proj = _emit_wgrads(ops().grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
+        del a
+        da = ops().grouped_gemm(dy, proj_ptrs, proj[0].shape[0], proj[0].shape[1], True, block_group)
+        dh = _act_bwd(da, h, ctx.act)
+        del da
+        g_fc = [None] * E
+        if any(needs[:E]):
+            g_fc = _emit_wgrads(ops().grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxs = ops().grouped_gemm(dh, fc_ptrs, fc[0].shape[0], fc[0].shape[1], True, block_group)
+            dx = ops().moe_gather_combine(dxs, row_of_pair, None, ctx.k)
+        dg = dgate.to(gates.dtype) if ctx.needs_input_grad[1] else None
+        return (dx, dg, None, None, None, *g_fc, *g_proj)
+
+
+def grouped_supported(x_flat, fc_weights, proj_weights, act: str) -> bool:
+    if act not in ("gelu", "swiglu") or not use_hip(x_flat) or x_flat.dtype != torch.bfloat16:
+        return False
+    if os.environ.get("DPA_MOE_GROUPED", "1") == "0":   # A/B switch: per-expert library GEMMs
+        return False
+    C = x_flat.shape[1]
+    U = proj_weights[0].shape[1]
+    ok = C % 128 == 0 and U % 128 == 0 and x_flat.is_contiguous()
+    for w in (*fc_weights, *proj_weights):
+        ok = ok and w.dtype == torch.bfloat16 and w.is_contiguous() and w.data_ptr() % 16 == 0
+    ok = ok and all(w.shape == fc_weights[0].shape for w in fc_weights)
+    ok = ok and all(w.shape == proj_weights[0].shape for w in proj_weights)
+    return ok
+
+
+def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str) -> torch.Tensor:
+    """sum_s gate[t, s] * expert_{idx[t, s]}(x[t]) for bias-free two-layer experts
+    (``act`` = "gelu" or "swiglu") on the grouped HIP kernels."""
+    return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, len(fc_weights), *fc_weights, *proj_weights)
+
+
+def grouped_experts_eager(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str) -> torch.Tensor:
+    """Plain PyTorch statement of ``grouped_experts`` (dense over experts; test oracle)."""
+    out = torch.zeros_like(x_flat)
+    for e, (wf, wp) in enumerate(zip(fc_weights, proj_weights)):
+        h = F.linear(x_flat, wf)
+        if act == "swiglu":
+            u, v = h.chunk(2, dim=-1)
+            a = F.silu(u) * v
+        else:
+            a = F.gelu(h)
+        y = F.linear(a, wp)
+        w = (topk_gates * (topk_indices == e)).sum(1, keepdim=True)
+        out = out + w.to(y.dtype) * y
+    return out

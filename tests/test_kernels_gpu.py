@@ -355,3 +355,87 @@ def test_colsum(M, N, dtype):
     assert rel_err(got, x.float().sum(0)) < 1e-4
     view = x[:, : N // 2 // 8 * 8]          # strided rows
     assert rel_err(hip().colsum(view), view.float().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("rows,N,K,kn", [(512, 256, 128, False), (1024, 3072, 768, False), (1024, 768, 3072, True),
+                                         (384, 200, 192, False), (384, 264, 128, True)])
+def test_grouped_gemm_forms(rows, N, K, kn):
+    """Every 128-row block multiplies with its own group's matrix; out-of-range groups are skipped."""
+    ops = _ops()
+    torch.manual_seed(0)
+    G = 3
+    a = torch.randn(rows, K, device=DEV, dtype=torch.bfloat16)
+    ws = [torch.randn((K, N) if kn else (N, K), device=DEV, dtype=torch.bfloat16) * 0.05 for _ in range(G)]
+    nb = rows // 128
+    bg = torch.tensor([(i * 7 + 1) % (G + 1) for i in range(nb)], dtype=torch.int32, device=DEV)  # value G = skip
+    ptrs = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device=DEV)
+    c = ops.grouped_gemm(a, ptrs, ws[0].shape[0], ws[0].shape[1], kn, bg)
+    for i in range(nb):
+        g = int(bg[i])
+        if g >= G:
+            continue
+        blk = a[i * 128:(i + 1) * 128].float()
+        ref = blk @ (ws[g].float() if kn else ws[g].float().t())
+        assert rel_err(c[i * 128:(i + 1) * 128], ref) < 6e-3, (i, g)
+
+
+def test_grouped_wgrad_segments():
+    ops = _ops()
+    torch.manual_seed(0)
+    N, K = 264, 256
+    seg_rows = torch.tensor([256, 0, 128, 1024], dtype=torch.int64, device=DEV)
+    seg_start = torch.cumsum(seg_rows, 0) - seg_rows
+    M = int(seg_rows.sum()) + 256            # trailing rows belong to no segment
+    dy = torch.randn(M, N, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    out = ops.grouped_wgrad(dy, x, seg_start, seg_rows)
+    for g in range(4):
+        s, r = int(seg_start[g]), int(seg_rows[g])
+        ref = dy[s:s + r].float().t() @ x[s:s + r].float()
+        if r == 0:
+            assert out[g].abs().max().item() == 0
+        else:
+            assert rel_err(out[g], ref) < 1e-5
+
+
+@pytest.mark.parametrize("act,E,k,Ntok,C,U", [("gelu", 8, 2, 4096, 768, 3072), ("swiglu", 3, 2, 1000, 256, 384),
+                                              ("gelu", 4, 1, 77, 128, 128)])
+def test_grouped_experts_fwd_bwd(act, E, k, Ntok, C, U):
+    """The padded grouped path equals the dense-over-experts fp32 statement, gradients included
+    (one expert receives no token at all in the small cases)."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(1)
+    fan = 2 * U if act == "swiglu" else U
+    x = torch.randn(Ntok, C, device=DEV, dtype=torch.bfloat16)
+    logits = torch.randn(Ntok, E, device=DEV)
+    if E <= 4:
+        logits[:, E - 1] = -1e9           # nobody routes to the last expert
+    gates, idx = torch.topk(logits, k, dim=1)
+    gates = torch.softmax(gates, dim=1).to(torch.bfloat16)
+    fcs = [(torch.randn(fan, C, device=DEV) * 0.04).to(torch.bfloat16) for _ in range(E)]
+    projs = [(torch.randn(C, U, device=DEV) * 0.04).to(torch.bfloat16) for _ in range(E)]
+    dout = torch.randn(Ntok, C, device=DEV, dtype=torch.bfloat16)
+
+    xr = x.float().requires_grad_()
+    gr = gates.float().requires_grad_()
+    fr = [w.float().requires_grad_() for w in fcs]
+    pr = [w.float().requires_grad_() for w in projs]
+    ref = ops.grouped_experts_eager(xr, idx, gr, fr, pr, act)
+    ref.backward(dout.float())
+
+    xh = x.clone().requires_grad_()
+    gh = gates.clone().requires_grad_()
+    fh = [w.clone().requires_grad_() for w in fcs]
+    ph = [w.clone().requires_grad_() for w in projs]
+    assert ops.grouped_supported(xh, fh, ph, act)
+    out = ops.grouped_experts(xh, idx, gh, fh, ph, act)
+    out.backward(dout)
+    assert rel_err(out, ref) < 1.5e-2
+    assert rel_err(xh.grad, xr.grad) < 1.5e-2
+    assert rel_err(gh.grad, gr.grad) < 2e-2
+    for e in range(E):
+        if fr[e].grad.abs().max() == 0:
+            assert fh[e].grad.abs().max() == 0 and ph[e].grad.abs().max() == 0
+            continue
+        assert rel_err(fh[e].grad, fr[e].grad) < 1.5e-2, e
+        assert rel_err(ph[e].grad, pr[e].grad) < 1.5e-2, e
