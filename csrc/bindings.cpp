@@ -499,7 +499,7 @@ Tensor grouped_wgrad(const Tensor& dy, const Tensor& x, const Tensor& seg_start,
                   seg_rows.is_cuda() && seg_rows.scalar_type() == at::kLong && seg_rows.is_contiguous() &&
                   seg_rows.numel() == G,
               "grouped_wgrad: segment tables are int64 cuda [G]");
-  Tensor out = at::zeros({G, N, K}, dy.options().dtype(at::kFloat));
+  Tensor out = at::empty({G, N, K}, dy.options().dtype(at::kFloat));
   dpa::gemm_grouped_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr<float>(),
                           (const long long*)seg_start.data_ptr<int64_t>(), (const long long*)seg_rows.data_ptr<int64_t>(),
                           (int)G, (int)N, (int)K, (int)M, cur_stream());

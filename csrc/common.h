@@ -119,6 +119,30 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return r;
 }
 
+// Eight consecutive elements held in their storage format: bf16 stays packed (4 registers per
+// vector), so values that must live across a reduction cost half the registers of fp32.
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = lo_bf16(v[i]);
+      o[2 * i + 1] = hi_bf16(v[i]);
+    }
+  }
+};
+template <> struct Vec8<float> {
+  float f[8];
+  __device__ __forceinline__ void load(const float* p) { load8(p, f); }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f[i];
+  }
+};
+
+
 // Bijective XCD-aware remap of a linear workgroup id: workgroups dealt round-robin to the
 // 8 XCDs are re-labelled so that each XCD (its own L2) works on a contiguous chunk of tiles.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

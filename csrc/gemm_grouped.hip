@@ -172,14 +172,14 @@ void gemm_grouped(const void* a, long long lda, const long long* w_ptrs, long lo
 // ------------------------------------------------------------------------------------------
 // Grouped weight gradient: dW_g[N, K] = A[seg_g, N]^T * B[seg_g, K], segment bounds on device.
 // One workgroup = (group, 128 x 128 output tile, split of the segment); fp32 partial tiles are
-// combined with float atomics into a zeroed fp32 buffer [ngroups, N, K].
+// combined with float atomics in the fp32 buffer [ngroups, N, K] (plain stores when a tile has one writer).
 // ------------------------------------------------------------------------------------------
 struct GroupedWgradArgs {
   const bf16_t* a;   // dY  [rows, N]
   long long lda;
   const bf16_t* b;   // X   [rows, K]
   long long ldb;
-  float* out;        // [ngroups, N, K], zero-initialised
+  float* out;        // [ngroups, N, K]
   const long long* seg_start;  // [ngroups] first row (multiple of 64)
   const long long* seg_rows;   // [ngroups] rows (multiple of 64, may be 0)
   int ngroups, N, K, splits;
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_wgrad_kernel(GroupedWgrad
   const long long t0 = split * per;
   long long t1 = t0 + per;
   if (t1 > ntile_all) t1 = ntile_all;
-  if (t0 >= t1) return;
+  const bool direct = p.splits == 1;   // sole writer of its tile: plain stores, zeros for an empty segment
+  if (t0 >= t1 && !direct) return;
   const int wn = wave >> 1, wk = wave & 1;
 
   f32x16 acc[2][2];
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_wgrad_kernel(GroupedWgrad
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n = n0 + 64 * wn + 32 * i + acc_row(q, hh);
-        if (n < p.N && kk < p.K) atomicAdd(out + (long long)n * p.K + kk, acc[i][j][q]);
+        if (n < p.N && kk < p.K) {
+          if (direct) out[(long long)n * p.K + kk] = acc[i][j][q];
+          else atomicAdd(out + (long long)n * p.K + kk, acc[i][j][q]);
+        }
       }
     }
 }
@@ -269,6 +273,7 @@ void gemm_grouped_wgrad(const void* a, long long lda, const void* b, long long l
   if (splits > max_s) splits = max_s;
   if (splits < 1) splits = 1;
   p.splits = splits;
+  if (splits > 1) hipMemsetAsync(out, 0, sizeof(float) * (size_t)ngroups * N * K, st);
   const dim3 grid(tiles * splits, ngroups), block(256);
   hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, grid, block, (size_t)(2 * 64 * 128 * 2), st, p);
 }

@@ -88,7 +88,7 @@ void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accu
 // N % 8 == 0, all rows 16-byte aligned.
 void gemm_grouped(const void* a, long long lda, const long long* w_ptrs, long long ldw, bool w_is_kn, void* c,
                   long long ldc, const int* block_group, int ngroups, int rows, int N, int K, hipStream_t st);
-// out[g, N, K] (fp32, caller-zeroed) += a[seg_g, N]^T * b[seg_g, K]; segment bounds (multiples of 64 rows)
+// out[g, N, K] (fp32, fully overwritten) = a[seg_g, N]^T * b[seg_g, K]; segment bounds (multiples of 64 rows)
 // are read from device memory. K % 128 == 0, N % 8 == 0.
 void gemm_grouped_wgrad(const void* a, long long lda, const void* b, long long ldb, float* out,
                         const long long* seg_start, const long long* seg_rows, int ngroups, int N, int K,

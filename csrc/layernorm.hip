@@ -116,6 +116,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const float mu = mean[row], rs = rstd[row];
     float g[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
+    Vec8<T> rv[NCH];   // residual-stream gradient, requested up front so it overlaps the row reduction
+    if (dres != nullptr) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * LPR;
+        if (c < nchunk) rv[i].load(dres + (size_t)row * C + c * 8);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * LPR;
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
         if (dres != nullptr) {
           float r[8];
-          load8(dres + (size_t)row * C + c * 8, r);
+          rv[i].get(r);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += r[j];
         }
@@ -315,7 +323,7 @@ int layernorm_max_cols() { return 16 * 64 * 8; }  // 8192; LDS in the backward: 
 
 int layernorm_bwd_parts(int rows) {
   int n = (rows + 7) / 8;
-  return n < 1 ? 1 : (n > 512 ? 512 : n);  // 2 workgroups (8 waves) per CU keep HBM busy
+  return n < 1 ? 1 : (n > 768 ? 768 : n);  // 3 workgroups (12 waves) per CU keep HBM busy
 }
 
 void layernorm_fwd(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out,

@@ -23,14 +23,40 @@ enum { XENT_FUSED = 0, XENT_STATS = 1, XENT_GRAD = 2 };
 constexpr int kXentThreads = 1024;
 constexpr int kXentMaxVec = 8;  // vectors of 8 logits cached per thread -> V <= 65536 in registers
 
+__device__ __forceinline__ float exp_diff(float d) { return d != d ? 0.f : __expf(d); }  // (-inf) - (-inf) -> 0
+
+// Block-wide log-sum-exp combine of per-thread (max, sum of exp(x - max)) pairs: one LDS round.
+__device__ __forceinline__ void block_lse(float& m, float& s, float* red /* 32 floats */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
+    const float M = fmaxf(m, m2);
+    s = s * exp_diff(m - M) + s2 * exp_diff(m2 - M);
+    m = M;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    red[wid] = m;
+    red[16 + wid] = s;
+  }
+  __syncthreads();
+  float M = red[0];
+  for (int i = 1; i < nw; ++i) M = fmaxf(M, red[i]);
+  float S = 0.f;
+  for (int i = 0; i < nw; ++i) S += red[16 + i] * exp_diff(red[i] - M);
+  m = M;
+  s = S;
+}
+
 template <typename T, int MODE, bool CACHED>
-__global__ __launch_bounds__(kXentThreads) void xent_kernel(T* __restrict__ logits, const long long* __restrict__ targets,
+__global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_kernel(T* __restrict__ logits, const long long* __restrict__ targets,
                                                             float* __restrict__ loss_rows, float* __restrict__ row_max,
                                                             float* __restrict__ row_sum, float* __restrict__ row_tgt,
                                                             const float* __restrict__ lse_in,
                                                             const float* __restrict__ grad_scale, int V, int ld,
                                                             int vocab_start, long long ignore_index, int write_grad) {
-  __shared__ float red[16];
+  __shared__ float red[32];
   const int row = blockIdx.x;
   T* lr = logits + (size_t)row * ld;
   const long long tgt = targets[row];
@@ -38,7 +64,7 @@ __global__ __launch_bounds__(kXentThreads) void xent_kernel(T* __restrict__ logi
   const int nvec = V >> 3;  // V is a multiple of 8 (checked on the host)
   const int tloc = (int)(tgt - vocab_start);
 
-  float cache[CACHED ? kXentMaxVec : 1][8];
+  Vec8<T> cache[CACHED ? kXentMaxVec : 1];
   float mx = -INFINITY;
   float sum = 0.f, lse = 0.f;
 
@@ -53,15 +79,29 @@ __global__ __launch_bounds__(kXentThreads) void xent_kernel(T* __restrict__ logi
       return;
     }
     if (CACHED) {
+      // thread-local max and sum first, then a single block-wide combine
 #pragma unroll
       for (int k = 0; k < kXentMaxVec; ++k) {
         const int i = threadIdx.x + k * kXentThreads;
         if (i < nvec) {
-          load8(lr + i * 8, cache[k]);
+          cache[k].load(lr + i * 8);
+          float x[8];
+          cache[k].get(x);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, cache[k][j]);
+          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, x[j]);
         }
       }
+#pragma unroll
+      for (int k = 0; k < kXentMaxVec; ++k) {
+        const int i = threadIdx.x + k * kXentThreads;
+        if (i < nvec) {
+          float x[8];
+          cache[k].get(x);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum += __expf(x[j] - mx);
+        }
+      }
+      block_lse(mx, sum, red);
     } else {
       for (int i = threadIdx.x; i < nvec; i += kXentThreads) {
         float x[8];
@@ -69,26 +109,15 @@ __global__ __launch_bounds__(kXentThreads) void xent_kernel(T* __restrict__ logi
 #pragma unroll
         for (int j = 0; j < 8; ++j) mx = fmaxf(mx, x[j]);
       }
-    }
-    mx = block_max(mx, red);
-    if (CACHED) {
-#pragma unroll
-      for (int k = 0; k < kXentMaxVec; ++k) {
-        const int i = threadIdx.x + k * kXentThreads;
-        if (i < nvec) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) sum += __expf(cache[k][j] - mx);
-        }
-      }
-    } else {
+      mx = block_max(mx, red);
       for (int i = threadIdx.x; i < nvec; i += kXentThreads) {
         float x[8];
         load8(lr + i * 8, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += __expf(x[j] - mx);
       }
+      sum = block_sum(sum, red);
     }
-    sum = block_sum(sum, red);
     if (MODE == XENT_STATS) {
       if (threadIdx.x == 0) {
         row_max[row] = mx;
@@ -117,10 +146,11 @@ __global__ __launch_bounds__(kXentThreads) void xent_kernel(T* __restrict__ logi
     for (int k = 0; k < kXentMaxVec; ++k) {
       const int i = threadIdx.x + k * kXentThreads;
       if (i < nvec) {
-        float o[8];
+        float x[8], o[8];
+        cache[k].get(x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float p = __expf(cache[k][j] - lse);
+          const float p = __expf(x[j] - lse);
           o[j] = (p - ((i * 8 + j) == tloc ? 1.f : 0.f)) * scale;
         }
         store8(lr + i * 8, o);
