@@ -50,11 +50,18 @@ def main():
     ap.add_argument("--act_recomp", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one line (the JSON result): everything else that native libraries print
+    # there (RCCL writes a version banner to stdout at communicator creation) is sent to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py measures on the GPU"
-    mode = args.mode if world > 1 else ("single" if args.mode == "ddp" else args.mode)
-    info = comm.init_distributed() if world > 1 else comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "none")
+    dist_job = world > 1 or comm.FORCE_COLLECTIVES   # DPA_FORCE_DIST=1: rehearse the RCCL paths with one rank
+    mode = args.mode if dist_job else ("single" if args.mode == "ddp" else args.mode)
+    info = comm.init_distributed() if dist_job else comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "none")
     torch.cuda.set_device(info.device)
     torch.manual_seed(1729 + info.rank)
 
@@ -74,10 +81,7 @@ def main():
     model = LLM(mc)
     total, active = model.get_num_params()
     flops_tok = model_flops_per_token(model, T)
-    if world > 1 or mode != "single":
-        engine = build_engine(mode, model, tc, info)
-    else:
-        engine = build_engine("single", model, tc, info)
+    engine = build_engine(mode, model, tc, info)
     optimizer = engine.configure_optimizers(learning_rate=tc.learning_rate)
 
     x, y = loader.next_batch()
@@ -110,7 +114,7 @@ def main():
     comm.barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=info.device)
-    if world > 1:
+    if dist_job:
         comm.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = el.item()
     final_loss = loss.item() * args.accum
@@ -131,8 +135,9 @@ def main():
                        "parallelism": f"{mode}{world}" if world > 1 else "single", "optimizer": "fused AdamW",
                        "grad_clip": tc.grad_clip},
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist_job:
         comm.shutdown()
 
 

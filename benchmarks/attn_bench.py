@@ -3,10 +3,12 @@ forward and of the backward (dK/dV + dQ kernels), counting the causal half of th
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+NIT = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 from distributed_pytorch_amd._ext import ops as hip
 
-def timeit(fn, n=20):
-    for _ in range(3): fn()
+def timeit(fn, n=None):
+    n = n or NIT
+    for _ in range(min(3, n)): fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(n):
@@ -16,7 +18,11 @@ def timeit(fn, n=20):
     ts.sort()
     return ts[len(ts) // 2]
 
-for (B, T, nh, nkv, hs) in [(32, 1024, 12, 12, 64), (16, 1024, 16, 16, 128), (8, 4096, 12, 12, 64), (16, 2048, 32, 8, 128)]:
+CASES = [(32, 1024, 12, 12, 64), (16, 1024, 16, 16, 128), (8, 4096, 12, 12, 64), (16, 2048, 32, 8, 128),
+         (64, 1024, 12, 12, 64)]
+if len(sys.argv) > 1:                      # python attn_bench.py <case index> [iterations]
+    CASES = [CASES[int(sys.argv[1])]]
+for (B, T, nh, nkv, hs) in CASES:
     q = torch.randn(B, T, nh, hs, device="cuda").to(torch.bfloat16)
     k = torch.randn(B, T, nkv, hs, device="cuda").to(torch.bfloat16)
     v = torch.randn(B, T, nkv, hs, device="cuda").to(torch.bfloat16)

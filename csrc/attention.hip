@@ -21,6 +21,8 @@
 //
 // Replaces `F.scaled_dot_product_attention(is_causal=True)` and the `repeat_interleave` GQA
 // expansion of the reference (reference: single-gpu/model.py:144-149).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "mfma_tiles.h"
@@ -277,31 +279,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int kv0 = t * 64;
     if (kv0 <= wave_qmax + off) {
       const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > p.Tk);
+      // The masked form (compare + select per score) only runs on tiles the diagonal crosses.
+      auto tile = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        f32x16 s, dp;
+        for (int sub = 0; sub < 2; ++sub) {
+          f32x16 s, dp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          s[i] = 0.f;
-          dp[i] = 0.f;
+          for (int i = 0; i < 16; ++i) {
+            s[i] = 0.f;
+            dp[i] = 0.f;
+          }
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s);
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(vb, sub * 32 + r, ks, hh), dof[ks], dp);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -lse2));
+            if (MASK && (kv0 + sub * 32 + acc_row(i, hh) > qlim)) pv = 0.f;
+            s[i] = pv * (dp[i] - dlt);  // dS^T
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bfrag dsb = acc_frag(s, s2);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+              dqacc[dt] = mfma32(tr_frag<HS>(kb, sub * 32, s2, dt, lane), dsb, dqacc[dt]);
+          }
         }
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s);
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(vb, sub * 32 + r, ks, hh), dof[ks], dp);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -lse2));
-          if (need_mask && (kv0 + sub * 32 + acc_row(i, hh) > qlim)) pv = 0.f;
-          s[i] = pv * (dp[i] - dlt);  // dS^T
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bfrag dsb = acc_frag(s, s2);
-#pragma unroll
-          for (int dt = 0; dt < ND; ++dt) dqacc[dt] = mfma32(tr_frag<HS>(kb, sub * 32, s2, dt, lane), dsb, dqacc[dt]);
-        }
-      }
+      };
+      if (need_mask) tile(std::true_type{});
+      else tile(std::false_type{});
     }
     if (t + 1 < ntiles) {
       char* nb = smem + ((t + 1) & 1) * 2 * TILE;
@@ -392,45 +401,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const char* dob = qb + TILE;
     const char* stb = qb + 2 * TILE;
     const int qt0 = q_start + (it % nqt) * 64;
+    auto block = [&](int sub, auto mask_tag) {
+      constexpr bool MASK = decltype(mask_tag)::value;
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[i] = 0.f;
+        dp[i] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(qb, sub * 32 + r, ks, hh), kf[ks], s);
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(dob, sub * 32 + r, ks, hh), vf[ks], dp);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int rr = sub * 32 + 8 * g4 + 4 * hh;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stb + rr * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stb + 256 + rr * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * g4 + j;
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[j]));
+          if (MASK && (key > qt0 + rr + j + off)) pv = 0.f;
+          s[i] = pv;                    // P
+          dp[i] = pv * (dp[i] - d4[j]);  // dS
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bfrag pb = acc_frag(s, s2);
+        const bfrag dsb = acc_frag(dp, s2);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          dvacc[dt] = mfma32(tr_frag<HS>(dob, sub * 32, s2, dt, lane), pb, dvacc[dt]);
+          dkacc[dt] = mfma32(tr_frag<HS>(qb, sub * 32, s2, dt, lane), dsb, dkacc[dt]);
+        }
+      }
+    };
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int qs0 = qt0 + sub * 32;
       if (qs0 + 31 + off >= kw0 && qs0 < p.Tq) {  // wave-uniform: some (query, key) pair is visible
-        f32x16 s, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          s[i] = 0.f;
-          dp[i] = 0.f;
-        }
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(qb, sub * 32 + r, ks, hh), kf[ks], s);
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(dob, sub * 32 + r, ks, hh), vf[ks], dp);
-        const bool need_mask = (kw0 + 31 > qs0 + off);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int rr = sub * 32 + 8 * g4 + 4 * hh;
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(stb + rr * 4);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(stb + 256 + rr * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int i = 4 * g4 + j;
-            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[j]));
-            if (need_mask && (key > qt0 + rr + j + off)) pv = 0.f;
-            s[i] = pv;                    // P
-            dp[i] = pv * (dp[i] - d4[j]);  // dS
-          }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bfrag pb = acc_frag(s, s2);
-          const bfrag dsb = acc_frag(dp, s2);
-#pragma unroll
-          for (int dt = 0; dt < ND; ++dt) {
-            dvacc[dt] = mfma32(tr_frag<HS>(dob, sub * 32, s2, dt, lane), pb, dvacc[dt]);
-            dkacc[dt] = mfma32(tr_frag<HS>(qb, sub * 32, s2, dt, lane), dsb, dkacc[dt]);
-          }
-        }
+        // The masked form (compare + select per score) only runs on blocks the diagonal crosses.
+        if (kw0 + 31 > qs0 + off) block(sub, std::true_type{});
+        else block(sub, std::false_type{});
       }
     }
     if (it + 1 < niter) commit((it + 1) & 1);

@@ -25,6 +25,16 @@ import torch
 import torch.distributed as dist
 
 
+# DPA_FORCE_DIST=1: create the process group and issue every collective even with one rank. A
+# single-GPU box can then rehearse the RCCL call paths (in-place reduce-scatter / all-gather views,
+# async work handles, stream ordering) exactly as a multi-rank job issues them.
+FORCE_COLLECTIVES = os.environ.get("DPA_FORCE_DIST", "0") == "1"
+
+
+def _single(group=None) -> bool:
+    return world_size(group) == 1 and not (FORCE_COLLECTIVES and dist.is_initialized())
+
+
 @dataclass
 class DistInfo:
     rank: int = 0
@@ -58,7 +68,7 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
     device = torch.device(f"cuda:{local_rank % ndev}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return DistInfo(0, 0, 1, device, "none")
     configure_rccl_env()
     backend = backend or ("nccl" if use_cuda else "gloo")
@@ -101,7 +111,7 @@ def _count(kind: str, t: torch.Tensor):
 
 
 def all_reduce(t: torch.Tensor, op=None, group=None, async_op: bool = False):
-    if world_size(group) == 1:
+    if _single(group):
         return _Done()
     _count("all_reduce", t)
     w = dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -109,7 +119,7 @@ def all_reduce(t: torch.Tensor, op=None, group=None, async_op: bool = False):
 
 
 def broadcast(t: torch.Tensor, src: int = 0, group=None, async_op: bool = False):
-    if world_size(group) == 1:
+    if _single(group):
         return _Done()
     _count("broadcast", t)
     w = dist.broadcast(t, src=src, group=group, async_op=async_op)
@@ -119,7 +129,7 @@ def broadcast(t: torch.Tensor, src: int = 0, group=None, async_op: bool = False)
 def reduce_scatter(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
     """out (numel n/W) = this rank's slice of the element-wise sum of ``inp`` (numel n)."""
     W = world_size(group)
-    if W == 1:
+    if _single(group):
         if out.data_ptr() != inp.data_ptr():
             out.copy_(inp)
         return _Done()
@@ -140,7 +150,7 @@ def all_gather(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool 
     """out (numel n*W) = concatenation of every rank's ``inp`` (numel n). ``inp`` may alias the
     local slice of ``out`` (in-place gather)."""
     W = world_size(group)
-    if W == 1:
+    if _single(group):
         if out.data_ptr() != inp.data_ptr():
             out.copy_(inp)
         return _Done()
@@ -159,8 +169,7 @@ def all_gather(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool 
 def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None,
                async_op: bool = False):
     """Row-wise all-to-all(v) of 2-D (or 1-D) tensors along dim 0."""
-    W = world_size(group)
-    if W == 1:
+    if _single(group):
         out.copy_(inp)
         return _Done()
     _count("all_to_all", inp)
@@ -169,5 +178,5 @@ def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=
 
 
 def barrier(group=None):
-    if world_size(group) > 1:
+    if not _single(group):
         dist.barrier(group=group)

@@ -43,7 +43,7 @@ class DDPEngine(Engine):
     def _make_hook(self, gi: int):
         def hook(param):
             self._pending[gi] -= 1
-            if self._pending[gi] == 0 and self.require_backward_grad_sync and self.world > 1:
+            if self._pending[gi] == 0 and self.require_backward_grad_sync and self._dist:
                 self._launch(gi)
         return hook
 
@@ -64,7 +64,7 @@ class DDPEngine(Engine):
         return comm.all_reduce(self.groups[gi].grad, group=self.group, async_op=True)
 
     def finish_grad_sync(self):
-        if self.world == 1:
+        if not self._dist:
             return
         if self.require_backward_grad_sync:
             # buckets whose hooks did not all fire (unused parameters) are reduced now, last first

@@ -71,6 +71,7 @@ class Engine(nn.Module):
         self.module = model.to(self.device)
         self.group = group
         self.world = comm.world_size(group)
+        self._dist = not comm._single(group)   # collectives are really issued (always when world > 1)
         self.rank = comm.get_rank(group)
         self.weight_decay = weight_decay
         self.betas, self.eps = betas, eps
@@ -87,7 +88,7 @@ class Engine(nn.Module):
     # ---- construction ---------------------------------------------------------------------
     def _sync_initial_state(self):
         """Every rank starts from rank 0's weights and buffers (seeds differ per rank)."""
-        if self.world == 1:
+        if not self._dist:
             return
         with torch.no_grad():
             for t in list(self.module.parameters()) + [b for b in self.module.buffers() if b is not None]:
@@ -212,7 +213,7 @@ class Engine(nn.Module):
         """Average the aux-free MoE routing biases over the data-parallel ranks, i.e. balance on
         the global expert load. (DDP in the reference re-broadcasts rank 0's buffer each forward,
         so only rank 0's load statistics survive there.)"""
-        if self.world == 1:
+        if not self._dist:
             return
         biases = [b for n, b in self.module.named_buffers() if n.endswith("expert_bias")]
         if not biases:
