@@ -188,32 +188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// delta[b, h, q] = sum_d dO * O
-// ------------------------------------------------------------------------------------------
-template <int HS>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
-  const long long total = (long long)p.B * p.Tq * p.nh;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int h = (int)(i % p.nh);
-  const long long bt = i / p.nh;
-  const int t = (int)(bt % p.Tq), b = (int)(bt / p.Tq);
-  const bf16_t* o = (const bf16_t*)p.o + b * p.o_bs + (long long)t * p.o_ts + h * HS;
-  const bf16_t* d = (const bf16_t*)p.dout + b * p.do_bs + (long long)t * p.do_ts + h * HS;
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < HS / 8; ++c) {
-    float a[8], g[8];
-    load8(o + c * 8, a);
-    load8(d + c * 8, g);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc += a[j] * g[j];
-  }
-  p.delta[((long long)b * p.nh + h) * p.Tq + t] = acc;
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward, dQ: one workgroup = 128 queries, sweeps the keys.
+// Backward, dQ: one workgroup = 128 queries, sweeps the keys. Also writes delta[b, h, q] = sum_d dO * O.
 // ------------------------------------------------------------------------------------------
 template <int HS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
@@ -239,14 +214,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     dof[ks] = zero_frag();
   }
   if (qrow < p.Tq) {
+    // delta = rowsum(dO * O) is formed here from the dO fragments the kernel holds anyway (each lane
+    // half owns half of the row) and published for the dK/dV kernel, which runs afterwards.
+    const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * HS + (long long)qrow * p.o_ts;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       qf[ks] = *reinterpret_cast<const bfrag*>(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8);
       dof[ks] = *reinterpret_cast<const bfrag*>(dop + (long long)qrow * p.do_ts + ks * 16 + hh * 8);
+      const u32x4 ov = *reinterpret_cast<const u32x4*>(orow + ks * 16 + hh * 8);
+      const u32x4 dv = __builtin_bit_cast(u32x4, dof[ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dlt += lo_bf16(ov[j]) * lo_bf16(dv[j]) + hi_bf16(ov[j]) * hi_bf16(dv[j]);
     }
     lse2 = p.lse[((long long)b * p.nh + h) * p.Tq + qrow] * kLog2e;
-    dlt = p.delta[((long long)b * p.nh + h) * p.Tq + qrow];
   }
+  dlt += __shfl_xor(dlt, 32, 64);
+  if (hh == 0 && qrow < p.Tq) p.delta[((long long)b * p.nh + h) * p.Tq + qrow] = dlt;
 
   int kv_end = q0 + 128 + off;
   if (kv_end > p.Tk) kv_end = p.Tk;
@@ -469,8 +452,10 @@ static void fwd_launch(const AttnParams& p, hipStream_t st) {
 
 template <int HS>
 static void bwd_launch(const AttnParams& p, hipStream_t st) {
-  const long long rows = (long long)p.B * p.Tq * p.nh;
-  hipLaunchKernelGGL((attn_delta_kernel<HS>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+  // dQ first: it also produces delta, which the dK/dV kernel consumes.
+  const int nqt = (p.Tq + 127) / 128;
+  const size_t lds_q = 4 * 64 * HS * 2;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HS>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
   const int nkt = (p.Tk + 127) / 128;
   const size_t lds_kv = 2 * (2 * 64 * HS * 2 + 512);
   static bool attr_set = false;
@@ -480,9 +465,6 @@ static void bwd_launch(const AttnParams& p, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
-  const int nqt = (p.Tq + 127) / 128;
-  const size_t lds_q = 4 * 64 * HS * 2;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HS>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
 }
 
 void attn_fwd(const AttnParams& p, hipStream_t st) {

@@ -33,6 +33,7 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from . import comm
 from .ddp import DDPEngine
 from .flat import FlatAdamW, FlatGroup, plan_groups, unique_named_parameters
@@ -90,23 +91,31 @@ class ExpertParallelDispatcher:
         R = recv.shape[0]
         seg_expert = torch.arange(per, device=recv.device).repeat(W)        # expert id of each (src, expert) segment
         row_expert = torch.repeat_interleave(seg_expert, recv_mat.reshape(-1), output_size=R)
-        perm = torch.argsort(row_expert, stable=True)
-        per_expert = recv_mat.sum(0).tolist()
-        grouped = recv[perm]
-        outs, start = [], 0
         lo = self.rank * per
-        for j, c in enumerate(per_expert):
-            if c:
-                outs.append(moe.experts[moe.n_shared + lo + j](grouped[start:start + c]))
-            start += c
-        if outs:
-            y_grouped = torch.cat(outs, dim=0)
+        local = [moe.experts[moe.n_shared + lo + j].expert for j in range(per)]
+        fcs, projs = [m.c_fc.weight for m in local], [m.c_proj.weight for m in local]
+        act = local[0].non_linearity
+        if not (moe.training and moe.config.dropout > 0) and ops.grouped_supported(recv, fcs, projs, act):
+            # grouped MFMA GEMMs over the padded expert-sorted layout: one launch per product for all
+            # local experts, nothing read back to the host
+            ones = torch.ones(R, 1, dtype=recv.dtype, device=recv.device)
+            y_recv = ops.grouped_experts(recv, row_expert.view(-1, 1), ones, fcs, projs, act)
         else:
-            y_grouped = grouped.new_zeros((0, x_flat.shape[1]))
-            # keep the local experts in the autograd graph so their (zero) gradients exist
-            y_grouped = y_grouped + 0.0 * sum(p.sum() for j in range(per)
-                                              for p in moe.experts[moe.n_shared + lo + j].parameters())
-        y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
+            perm = torch.argsort(row_expert, stable=True)
+            per_expert = recv_mat.sum(0).tolist()
+            grouped = recv[perm]
+            outs, start = [], 0
+            for j, c in enumerate(per_expert):
+                if c:
+                    outs.append(local[j](grouped[start:start + c]))
+                start += c
+            if outs:
+                y_grouped = torch.cat(outs, dim=0)
+            else:
+                y_grouped = grouped.new_zeros((0, x_flat.shape[1]))
+                # keep the local experts in the autograd graph so their (zero) gradients exist
+                y_grouped = y_grouped + 0.0 * sum(p.sum() for m in local for p in m.parameters())
+            y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
         y_back = all_to_all_rows(y_recv, recv_h, counts_h, self.group)
         gs = topk_gates.reshape(-1)[order].unsqueeze(1)
         return torch.zeros_like(x_flat).index_add_(0, tok, (y_back * gs).to(x_flat.dtype))
@@ -175,7 +184,6 @@ class EPEngine(DDPEngine):
 
     def _compute_norm(self):
         """||g||^2 = dense part (replicated, counted once) + sum over ranks of the expert parts."""
-        from .. import ops
         dense = torch.zeros_like(self._norm2)
         first = True
         for g in self.groups[:self._n_dense_groups]:
@@ -201,8 +209,6 @@ class EPEngine(DDPEngine):
         cfg = self.module.config
         per = (cfg.n_exp - cfg.n_shared) // self.world
         names = [k for k, _ in self.module.named_parameters(remove_duplicate=False)]
-        tied = {k: n2 for k, p in self.module.named_parameters(remove_duplicate=False)
-                for n2, p2 in by_name.items() if False}
         params = dict(self.module.named_parameters(remove_duplicate=False))
         first_name = {}
         for k, p in params.items():

@@ -1,0 +1,109 @@
+"""RCCL call paths on one GPU: a one-rank ``nccl`` process group with every collective really
+issued (``comm.FORCE_COLLECTIVES``), so the in-place reduce-scatter / all-gather views, the async
+work handles and the stream ordering of the engines are exercised exactly as a multi-rank job
+issues them; and the ``bench.py`` launch line of the multi-GPU runs with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    import torch.distributed as dist
+    from distributed_pytorch_amd.parallel import comm
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    old = comm.FORCE_COLLECTIVES
+    comm.FORCE_COLLECTIVES = True
+    yield comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "nccl")
+    comm.FORCE_COLLECTIVES = old
+    dist.destroy_process_group()
+
+
+def _run(engine, cfg, steps=6):
+    torch.manual_seed(3)
+    x = torch.randint(0, cfg.vocab_size, (8, 256), device="cuda")
+    losses = []
+    for _ in range(steps):
+        engine.zero_grad()
+        for micro in range(2):
+            engine.require_backward_grad_sync = micro == 1
+            _, loss, _ = engine(x, x.roll(-1, 1))
+            (loss / 2).backward()
+        engine.clip_grad_norm_(1.0)
+        engine.step(3e-3)
+        losses.append(loss.item())
+    return losses
+
+
+@pytest.mark.parametrize("mode", ["ddp", "zero1", "zero2", "fsdp"])
+def test_engine_through_rccl_matches_single(one_rank_group, mode):
+    from distributed_pytorch_amd.config import LLMconfig, Trainconfig
+    from distributed_pytorch_amd.models.llm import LLM
+    from distributed_pytorch_amd.parallel import comm
+    from distributed_pytorch_amd.trainer import build_engine
+    cfg = LLMconfig(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="mha",
+                    pos_emb="learn", non_linearity="gelu").finalize()
+    tc = Trainconfig(dtype="bf16", learning_rate=1e-3, bucket_mb=0.5)
+    torch.manual_seed(1)
+    ref = _run(build_engine("single", LLM(cfg), tc, one_rank_group), cfg)
+    before = dict(comm.STATS)
+    torch.manual_seed(1)
+    eng = build_engine(mode, LLM(cfg), tc, one_rank_group)
+    assert eng._dist, "collectives must really be issued in this test"
+    got = _run(eng, cfg)
+    moved = {k: comm.STATS[k] - before[k] for k in before}
+    assert sum(moved.values()) > 0, "no collective was issued"
+    if mode == "zero2":
+        assert moved["reduce_scatter"] > 0 and moved["all_gather"] > 0
+    if mode == "fsdp":
+        assert moved["reduce_scatter"] > 0 and moved["all_gather"] > 0
+    for a, b in zip(got, ref):
+        assert abs(a - b) < 2e-2 * abs(b) + 1e-3, (mode, got, ref)
+
+
+def test_expert_parallel_through_rccl(one_rank_group):
+    from distributed_pytorch_amd.config import LLMconfig
+    from distributed_pytorch_amd.models.llm import LLM
+    from distributed_pytorch_amd.parallel import comm
+    from distributed_pytorch_amd.parallel.engine import Engine
+    from distributed_pytorch_amd.parallel.ep import EPEngine
+    cfg = LLMconfig(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="mha",
+                    pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2).finalize()
+    torch.manual_seed(1)
+    ref = _run(Engine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3), cfg)
+    before = comm.STATS["all_to_all"]
+    torch.manual_seed(1)
+    got = _run(EPEngine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3), cfg)
+    assert comm.STATS["all_to_all"] > before
+    for a, b in zip(got, ref):
+        assert abs(a - b) < 3e-2 * abs(b) + 1e-3, (got, ref)
+
+
+@pytest.mark.parametrize("mode", ["ddp", "fsdp"])
+def test_bench_launch_line_prints_one_json_line(mode):
+    """The multi-GPU launch line with one rank: stdout is exactly the JSON result."""
+    env = dict(os.environ, DPA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29579", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--batch", "4", "--mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in out
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["seq_len"] == 1024 and out["config"]["global_batch"] == 4
