@@ -295,6 +295,90 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// 256 x 256 output tile, 4 waves in 2 x 2, each wave 128 x 128 (4 x 4 accumulator tiles in AGPRs).
+// Transposed LDS reads deliver half the bytes per cycle of row reads, and with both operands
+// token-major every MFMA operand of this product needs one; a 128 x 128 wave tile feeds 16 MFMAs
+// from 8 operand fragments (the 128 x 64 wave tile of wgrad2_kernel: 8 from 6), which moves the
+// LDS ceiling from about half to about three quarters of the MFMA rate. One workgroup per CU;
+// two 64 KiB stages, filled by LDS-DMA issued from inline assembly (see dma_subtile_asm) so that
+// the transfer of tile t+1 stays in flight during the MFMAs of tile t.
+template <bool ACCUM>
+__global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                        float* __restrict__ slabs, int M, int N, int K,
+                                                        long long ldy, long long ldx, int splits, int mper) {
+  constexpr int SUB = 64 * 128 * 2;  // 16 KiB
+  constexpr int STAGE = 4 * SUB;     // 64 KiB: two dY sub-tiles + two X sub-tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int tiles_k = K / 256;
+  const int id = blockIdx.x;
+  const int split = id % splits, tile = id / splits;
+  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int m_begin = split * mper;
+  int m_end = m_begin + mper;
+  if (m_end > M) m_end = M;
+  const int ntiles = (m_end > m_begin) ? (m_end - m_begin) / 64 : 0;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  auto issue = [&](int t, int stage) {
+    const long long m = m_begin + (long long)t * 64;
+    const unsigned base = lds0 + stage * STAGE;
+    dma_subtile_asm(dy + m * ldy + n0, ldy, 128, base, wave, lane);
+    dma_subtile_asm(dy + m * ldy + n0 + 128, ldy, 128, base + SUB, wave, lane);
+    dma_subtile_asm(x + m * ldx + k0, ldx, 128, base + 2 * SUB, wave, lane);
+    dma_subtile_asm(x + m * ldx + k0 + 128, ldx, 128, base + 3 * SUB, wave, lane);
+  };
+  if (ntiles > 0) issue(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed (this wave's DMAs drained, then everybody's through the barrier); the same
+    // barrier proves that every wave is done reading the stage that tile t+1 is about to overwrite
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+    const char* ya = smem + (t & 1) * STAGE + wn * SUB;
+    const char* xb = smem + (t & 1) * STAGE + (2 + wk) * SUB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bfrag a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = tr_frag<128>(ya, 0, s, i, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = tr_frag<128>(xb, 0, s, j, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+  }
+
+  float* out = slabs + (ACCUM ? 0 : (long long)split * N * K);
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + 128 * wk + 32 * j + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 128 * wn + 32 * i + acc_row(r, hh);
+        float* p = out + (long long)n * K + kk;
+        if (ACCUM) *p += acc[i][j][r];
+        else *p = acc[i][j][r];
+      }
+    }
+}
+
 // out (bf16 or fp32) = [out +] sum over `nslabs` slabs of ws
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ ws, T* __restrict__ out,
@@ -348,9 +432,20 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 
 bool wgrad2_ok(int M, int N, int K) { return M % 64 == 0 && M >= 64 && N % 8 == 0 && K % kW2K == 0; }
 
-int g_wgrad2_stages = 1;   // tuning knob (benchmarks): 1 = single LDS buffer, 2 = double-buffered, 3 = ring
+int g_wgrad2_stages = 4;   // 4 = 256x256 kernel where the shape allows (else single buffer); 1/2/3 = wgrad2_kernel variants (benchmarks)
+
+static bool use_wgrad3(int M, int N, int K) {
+  return g_wgrad2_stages == 4 && N % 256 == 0 && K % 256 == 0 && M >= 1024;
+}
 
 int wgrad2_splits(int M, int N, int K) {
+  if (use_wgrad3(M, N, K)) {
+    const int t3 = (N / 256) * (K / 256);
+    int s3 = 256 / t3;                   // one workgroup per CU
+    if (s3 > M / 512) s3 = M / 512;      // at least 8 LDS tiles per workgroup
+    if (s3 > 64) s3 = 64;
+    return s3 < 1 ? 1 : s3;
+  }
   const int tiles = ((N + kW2N - 1) / kW2N) * (K / kW2K);
   int s = (g_wgrad2_stages == 1 ? 512 : 256) / tiles;   // one round of the workgroups that fit per CU
   const int max_s = M / 256;           // at least 4 LDS tiles per workgroup
@@ -369,8 +464,24 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
   if (M == 0) return;
   const int sp = splits > 0 ? splits : 1;
   int mper = (M / 64 + sp - 1) / sp * 64;
+  if (use_wgrad3(M, N, K)) {
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr3 = true;
+    }
+    const dim3 grid3((N / 256) * (K / 256) * sp), block3(256);
+    if (splits > 0)
+      hipLaunchKernelGGL((wgrad3_kernel<false>), grid3, block3, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M,
+                         N, K, ldy, ldx, sp, mper);
+    else
+      hipLaunchKernelGGL((wgrad3_kernel<true>), grid3, block3, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M,
+                         N, K, ldy, ldx, sp, mper);
+    return;
+  }
   const dim3 grid(((N + kW2N - 1) / kW2N) * (K / kW2K) * sp), block(256);
-  const int stages = g_wgrad2_stages;
+  const int stages = g_wgrad2_stages == 4 ? 1 : g_wgrad2_stages;
   const size_t lds = (size_t)stages * 3 * 64 * 128 * 2;  // 48 KiB per stage
   static bool attr = false;
   if (!attr) {
