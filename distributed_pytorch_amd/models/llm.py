@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 import threading
 
 import torch
@@ -453,7 +454,7 @@ class LLM(nn.Module):
         self.apply(self._init_weights)
         self.VAL_RUN = False
         self.materialize_logits = False   # True: also return [B, T, V] logits when targets are given
-        self.loss_chunk_rows = 8192
+        self.loss_chunk_rows = int(os.environ.get("DPA_LOSS_CHUNK", "8192"))
         self.print_act_recomp = config.act_recomp
         self.print_fused_adamw = True
         self._pos_cache = None
