@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--bucket_mb", type=float, default=48.0)
     ap.add_argument("--act_recomp", action="store_true")
+    ap.add_argument("--hip_graph", action="store_true", help="replay the optimizer step from one hipGraph (1 GPU)")
     args = ap.parse_args()
 
     # stdout carries exactly one line (the JSON result): everything else that native libraries print
@@ -85,6 +86,19 @@ def main():
     optimizer = engine.configure_optimizers(learning_rate=tc.learning_rate)
 
     x, y = loader.next_batch()
+    graphed = None
+    if args.hip_graph:
+        from distributed_pytorch_amd.parallel.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(engine, args.accum, tc.grad_clip, warmup=min(2, max(args.warmup - 1, 0)))
+
+    def graph_step(it: int):
+        nonlocal x, y
+        batches = [(x, y)]
+        for _ in range(args.accum - 1):
+            batches.append(loader.next_batch())
+        loss = graphed.step(batches, get_lr(it, tc)) / args.accum
+        x, y = loader.next_batch()
+        return loss
 
     def step(it: int):
         nonlocal x, y
@@ -103,6 +117,8 @@ def main():
         optimizer.step()
         return loss
 
+    if graphed is not None:
+        step = graph_step   # noqa: F811 - same contract, submitted as one graph
     for it in range(args.warmup):
         loss = step(it)
     comm.barrier()
@@ -133,7 +149,7 @@ def main():
             "config": {"model": args.model, "params": total, "global_batch": global_batch, "micro_batch": B,
                        "seq_len": T, "grad_accum": args.accum,
                        "parallelism": f"{mode}{world}" if world > 1 else "single", "optimizer": "fused AdamW",
-                       "grad_clip": tc.grad_clip},
+                       "grad_clip": tc.grad_clip, "hip_graph": bool(args.hip_graph)},
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

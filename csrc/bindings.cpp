@@ -95,7 +95,8 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor&
 // ---------------------------------------------------------------------------------------
 void adamw_step(Tensor master, Tensor m, Tensor v, const Tensor& grad, const std::optional<Tensor>& param_out,
                 std::vector<int64_t> seg_ends, std::vector<double> seg_wds, double lr, double beta1, double beta2,
-                double eps, int64_t step, const std::optional<Tensor>& norm2, double max_norm, double grad_mul) {
+                double eps, int64_t step, const std::optional<Tensor>& norm2, double max_norm, double grad_mul,
+                const std::optional<Tensor>& dyn) {
   const int64_t n = master.numel();
   TORCH_CHECK(n % 8 == 0, "adamw: flat buffers must be padded to a multiple of 8 elements");
   for (const Tensor* t : {&master, &m, &v}) {
@@ -125,13 +126,19 @@ void adamw_step(Tensor master, Tensor m, Tensor v, const Tensor& grad, const std
     TORCH_CHECK(norm2->is_cuda() && norm2->scalar_type() == at::kFloat && norm2->numel() == 1, "norm2: 1 fp32");
     n2 = norm2->data_ptr<float>();
   }
+  const float* dynp = nullptr;
+  if (dyn.has_value()) {
+    TORCH_CHECK(dyn->is_cuda() && dyn->scalar_type() == at::kFloat && dyn->numel() == 3 && dyn->is_contiguous(),
+                "dyn: 3 fp32 {lr, bc1, bc2_sqrt} on the device");
+    dynp = dyn->data_ptr<float>();
+  }
   if (n == 0) return;
   const float bc1 = 1.f - (float)std::pow(beta1, (double)step);
   const float bc2s = (float)std::sqrt(1.0 - std::pow(beta2, (double)step));
   dpa::adamw_step(master.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(), grad.data_ptr(), is_bf16(grad),
                   param_out.has_value() ? param_out->data_ptr() : nullptr,
                   param_out.has_value() ? is_bf16(*param_out) : false, n, segs, (float)lr, (float)beta1,
-                  (float)beta2, (float)eps, bc1, bc2s, n2, (float)max_norm, (float)grad_mul, cur_stream());
+                  (float)beta2, (float)eps, bc1, bc2s, n2, (float)max_norm, (float)grad_mul, dynp, cur_stream());
 }
 
 void sumsq(const Tensor& g, Tensor out, bool accumulate) {
@@ -579,7 +586,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres) -> (Tensor, Tensor, Tensor)");
   m.def("adamw_step(Tensor(a!) master, Tensor(b!) m, Tensor(c!) v, Tensor grad, Tensor? param_out, int[] seg_ends, "
         "float[] seg_wds, float lr, float beta1, float beta2, float eps, int step, Tensor? norm2, float max_norm, "
-        "float grad_mul) -> ()");
+        "float grad_mul, Tensor? dyn) -> ()");
   m.def("sumsq(Tensor g, Tensor(a!) out, bool accumulate) -> ()");
   m.def("xent_fused(Tensor(a!) logits, Tensor targets, Tensor grad_scale, int ignore_index, bool write_grad) -> Tensor");
   m.def("xent_stats(Tensor logits, Tensor targets, int vocab_start, int ignore_index) -> (Tensor, Tensor, Tensor)");

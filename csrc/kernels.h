@@ -23,7 +23,8 @@ struct AdamSegs {
 };
 void adamw_step(float* master, float* m, float* v, const void* grad, bool grad_bf16, void* param_out,
                 bool param_bf16, long long n, const AdamSegs& segs, float lr, float beta1, float beta2, float eps,
-                float bc1, float bc2_sqrt, const float* norm2, float max_norm, float grad_mul, hipStream_t st);
+                float bc1, float bc2_sqrt, const float* norm2, float max_norm, float grad_mul, const float* dyn,
+                hipStream_t st);  // dyn: optional device {lr, bc1, bc2_sqrt} overriding the arguments
 int sumsq_parts(long long n);
 void sumsq(const void* g, bool is_bf16, long long n, float* partials, float* out, bool accumulate, hipStream_t st);
 

@@ -20,7 +20,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
                                                     PT* __restrict__ param_out, long long n, AdamSegs segs,
                                                     float lr, float beta1, float beta2, float eps, float bc1,
                                                     float bc2_sqrt, const float* __restrict__ norm2,
-                                                    float max_norm, float grad_mul) {
+                                                    float max_norm, float grad_mul,
+                                                    const float* __restrict__ dyn) {
+  // Step-dependent scalars read from device memory (lr, 1 - beta1^t, sqrt(1 - beta2^t)) when the
+  // step is replayed from a captured graph, where kernel arguments are frozen at capture time.
+  if (dyn != nullptr) {
+    lr = dyn[0];
+    bc1 = dyn[1];
+    bc2_sqrt = dyn[2];
+  }
   float gscale = grad_mul;
   if (norm2 != nullptr) {
     const float n2 = *norm2;
@@ -100,11 +108,12 @@ static int flat_grid(long long n) {
 
 void adamw_step(float* master, float* m, float* v, const void* grad, bool grad_bf16, void* param_out,
                 bool param_bf16, long long n, const AdamSegs& segs, float lr, float beta1, float beta2, float eps,
-                float bc1, float bc2_sqrt, const float* norm2, float max_norm, float grad_mul, hipStream_t st) {
+                float bc1, float bc2_sqrt, const float* norm2, float max_norm, float grad_mul, const float* dyn,
+                hipStream_t st) {
   const dim3 grid(flat_grid(n)), block(256);
 #define DPA_LAUNCH(GT, PT)                                                                                    \
   hipLaunchKernelGGL((adamw_kernel<GT, PT>), grid, block, 0, st, master, m, v, (const GT*)grad, (PT*)param_out, \
-                     n, segs, lr, beta1, beta2, eps, bc1, bc2_sqrt, norm2, max_norm, grad_mul)
+                     n, segs, lr, beta1, beta2, eps, bc1, bc2_sqrt, norm2, max_norm, grad_mul, dyn)
   if (grad_bf16) {
     if (param_bf16) DPA_LAUNCH(bf16_t, bf16_t);
     else DPA_LAUNCH(bf16_t, float);

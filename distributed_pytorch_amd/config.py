@@ -7,7 +7,7 @@ deliberate:
 * ``--total_batch_size_str`` is evaluated by a small arithmetic parser instead of ``eval``
   (``"2**14"`` and ``"16*1024"`` still work; arbitrary Python does not).
 * Extra, optional flags (all default to the reference behaviour when absent) select the
-  MI355X-specific machinery: ``--dtype``, ``--grad_dtype``, ``--bucket_mb``, ``--profile``,
+  MI355X-specific machinery: ``--dtype``, ``--grad_dtype``, ``--bucket_mb``, ``--profile``, ``--hip_graph``,
   ``--resume``, ``--metrics_jsonl``, ``--synthetic_tokens`` and friends.
 """
 from __future__ import annotations
@@ -108,6 +108,7 @@ class Trainconfig:
     profile: bool = False
     log_interval: int = 1
     sync_loss_every: int = 1          # host reads the loss every N steps (1 = reference behaviour)
+    hip_graph: bool = False           # capture the whole optimizer step in one hipGraph (single GPU)
 
     def to_dict(self) -> dict:
         return asdict(self)
@@ -225,6 +226,7 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--profile", action="store_true")
     p.add_argument("--log_interval", type=int, default=tc.log_interval)
     p.add_argument("--sync_loss_every", type=int, default=tc.sync_loss_every)
+    p.add_argument("--hip_graph", action="store_true")
     return p
 
 

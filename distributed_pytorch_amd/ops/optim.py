@@ -33,13 +33,15 @@ def sumsq(g: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch
 def adamw_step(master: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, grad: torch.Tensor,
                param_out: torch.Tensor | None, segments: Sequence[tuple[int, float]], lr: float, beta1: float,
                beta2: float, eps: float, step: int, norm2: torch.Tensor | None = None, max_norm: float = 0.0,
-               grad_mul: float = 1.0) -> None:
+               grad_mul: float = 1.0, dyn: torch.Tensor | None = None) -> None:
     """One AdamW step over a flat range.
 
     ``grad`` may be bf16 or fp32. If ``norm2`` (device scalar holding the squared global
     gradient norm *before* ``grad_mul``) is given, gradients are clipped to ``max_norm`` (when
     > 0) and the whole update is skipped when it is not finite. ``param_out`` receives the
-    updated weights in its own dtype (the bf16 compute copy)."""
+    updated weights in its own dtype (the bf16 compute copy). ``dyn`` (device fp32
+    ``[lr, 1 - beta1^t, sqrt(1 - beta2^t)]``) overrides ``lr`` / ``step`` from device memory, which a
+    step replayed from a captured graph needs (kernel arguments are frozen at capture)."""
     n = master.numel()
     if n == 0:
         return
@@ -47,7 +49,7 @@ def adamw_step(master: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Te
         ends = [int(e) for e, _ in segments]
         wds = [float(w) for _, w in segments]
         ops().adamw_step(master, exp_avg, exp_avg_sq, grad, param_out, ends, wds, lr, beta1, beta2, eps, step,
-                         norm2, max_norm, grad_mul)
+                         norm2, max_norm, grad_mul, dyn)
         return
     # ---- eager path (CPU plumbing / tests) ----
     g = grad.float() * grad_mul
@@ -63,6 +65,8 @@ def adamw_step(master: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Te
     exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
     bc1 = 1 - beta1 ** step
     bc2s = math.sqrt(1 - beta2 ** step)
+    if dyn is not None:
+        lr, bc1, bc2s = (float(v) for v in dyn.tolist())
     start = 0
     for end, wd in segments:
         sl = slice(start, end)

@@ -81,6 +81,7 @@ class Engine(nn.Module):
         self._max_norm = 0.0
         self._norm2 = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._have_norm = False
+        self._dyn = None   # device {lr, bc1, bc2_sqrt} while a captured step is recorded / replayed (parallel/graph.py)
         self._sync_initial_state()
         self._build_storage()
         self.optimizer = _OptimizerFacade(self, lr)
@@ -204,7 +205,7 @@ class Engine(nn.Module):
     def _apply_updates(self, lr: float):
         for g, o in zip(self.groups, self.optims):
             o.step(g.grad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
-                   self._grad_mul())
+                   self._grad_mul(), self._dyn)
 
     def _post_step(self):
         self._sync_moe_bias()

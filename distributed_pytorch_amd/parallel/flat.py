@@ -127,9 +127,10 @@ class FlatAdamW:
         self.segs = group.segments(self.lo, self.hi)
 
     def step(self, grad: torch.Tensor, param_out: torch.Tensor | None, lr: float, step: int,
-             norm2: torch.Tensor | None = None, max_norm: float = 0.0, grad_mul: float = 1.0):
+             norm2: torch.Tensor | None = None, max_norm: float = 0.0, grad_mul: float = 1.0,
+             dyn: torch.Tensor | None = None):
         ops.adamw_step(self.master, self.exp_avg, self.exp_avg_sq, grad, param_out, self.segs, lr, self.betas[0],
-                       self.betas[1], self.eps, step, norm2, max_norm, grad_mul)
+                       self.betas[1], self.eps, step, norm2, max_norm, grad_mul, dyn)
 
     def state_dict(self):
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

@@ -127,6 +127,12 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         start_iter = load_resume(tc.resume, engine, (train_loader, val_loader), info.rank) + 1
         say(f"resumed from {tc.resume} at iteration {start_iter}")
 
+    graphed = None
+    if tc.hip_graph and device.type == "cuda" and not engine._dist:
+        from .parallel.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(engine, grad_accum_steps, tc.grad_clip)
+        say("Using hipGraph capture of the optimizer step")
+
     sink = JsonlSink(tc.metrics_jsonl if master else "")
     timer = PhaseTimer(tc.profile)
     train_loss_stats, valrun_val, valrun_train = [], [], []
@@ -150,7 +156,15 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
                 f"dt {1000 * (b - a):.4f}ms")
             t0 = b
 
-        for micro_step in range(grad_accum_steps):
+        if graphed is not None:
+            batches = [(x, y)]
+            for _ in range(grad_accum_steps - 1):
+                batches.append(train_loader.next_batch())
+            loader_state = train_loader.state_dict()
+            with timer.phase("graph"):
+                loss = graphed.step(batches, lr) / grad_accum_steps
+            x, y = train_loader.next_batch()
+        for micro_step in range(grad_accum_steps if graphed is None else 0):
             engine.require_backward_grad_sync = (micro_step == grad_accum_steps - 1)
             with timer.phase("forward"):
                 _, loss, _ = engine(x, y)
@@ -160,10 +174,11 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
             with timer.phase("backward"):
                 loss.backward()
 
-        with timer.phase("optimizer"):
-            if tc.grad_clip != 0.0:
-                engine.clip_grad_norm_(tc.grad_clip)
-            optimizer.step()
+        if graphed is None:
+            with timer.phase("optimizer"):
+                if tc.grad_clip != 0.0:
+                    engine.clip_grad_norm_(tc.grad_clip)
+                optimizer.step()
 
         read_loss = (it % max(tc.sync_loss_every, 1) == 0) or it == tc.max_iters
         if read_loss:
