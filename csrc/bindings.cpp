@@ -567,9 +567,50 @@ std::tuple<Tensor, Tensor> moe_combine_bwd(const Tensor& dout, const Tensor& y, 
   return {dy, dgate};
 }
 
+// (idx int64 [N, k], gates fp32 [N, k]) = top-k routing of fp32 logits [N, E] (+ optional selection bias [E]).
+std::tuple<Tensor, Tensor> moe_topk_gate(const Tensor& logits, const std::optional<Tensor>& bias, int64_t k) {
+  TORCH_CHECK(logits.is_cuda() && logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.is_contiguous(),
+              "moe_topk_gate: fp32 contiguous [tokens, experts]");
+  const int64_t N = logits.size(0), E = logits.size(1);
+  TORCH_CHECK(E >= 1 && E <= 64 && k >= 1 && k <= 8 && k <= E, "moe_topk_gate: E <= 64 and k <= min(8, E)");
+  const float* bp = nullptr;
+  if (bias.has_value()) {
+    TORCH_CHECK(bias->is_cuda() && bias->scalar_type() == at::kFloat && bias->is_contiguous() && bias->numel() == E,
+                "moe_topk_gate: bias is fp32 [experts]");
+    bp = bias->data_ptr<float>();
+  }
+  Tensor idx = at::empty({N, k}, logits.options().dtype(at::kLong));
+  Tensor gates = at::empty({N, k}, logits.options());
+  dpa::moe_topk_gate(logits.data_ptr<float>(), bp, (long long*)idx.data_ptr<int64_t>(), gates.data_ptr<float>(), N,
+                     (int)E, (int)k, cur_stream());
+  return {idx, gates};
+}
+
+// (row_of_pair [npairs] int64, block_group [rows / 128] int32, seg_start, seg_rows, counts [E] int64)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> moe_plan(const Tensor& idx, int64_t n_experts, int64_t rows) {
+  TORCH_CHECK(idx.is_cuda() && idx.scalar_type() == at::kLong && idx.is_contiguous(), "moe_plan: int64 expert ids");
+  TORCH_CHECK(n_experts >= 1 && n_experts <= 64 && rows % 128 == 0, "moe_plan: E <= 64, rows % 128 == 0");
+  const int64_t npairs = idx.numel();
+  TORCH_CHECK(rows >= npairs + n_experts * 127, "moe_plan: row bound too small for the padded layout");
+  auto opt = idx.options();
+  Tensor row_of_pair = at::empty({npairs}, opt);
+  Tensor block_group = at::empty({rows / 128}, opt.dtype(at::kInt));
+  Tensor seg_start = at::empty({n_experts}, opt), seg_rows = at::empty({n_experts}, opt);
+  Tensor counts = at::empty({n_experts}, opt);
+  const int nb = dpa::moe_plan_blocks(npairs);
+  Tensor hist = at::empty({std::max<int64_t>(nb, 1) * n_experts}, opt.dtype(at::kInt));
+  dpa::moe_plan((const long long*)idx.data_ptr<int64_t>(), npairs, (int)n_experts, (int)(rows / 128),
+                hist.data_ptr<int>(), (long long*)row_of_pair.data_ptr<int64_t>(), block_group.data_ptr<int>(),
+                (long long*)seg_start.data_ptr<int64_t>(), (long long*)seg_rows.data_ptr<int64_t>(),
+                (long long*)counts.data_ptr<int64_t>(), cur_stream());
+  return {row_of_pair, block_group, seg_start, seg_rows, counts};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dpa, m) {
+  m.def("moe_topk_gate(Tensor logits, Tensor? bias, int k) -> (Tensor, Tensor)");
+  m.def("moe_plan(Tensor idx, int n_experts, int rows) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("grouped_gemm(Tensor a, Tensor w_ptrs, int w_rows, int w_cols, bool w_is_kn, Tensor block_group) -> Tensor");
   m.def("grouped_wgrad(Tensor dy, Tensor x, Tensor seg_start, Tensor seg_rows) -> Tensor");
   m.def("moe_scatter_rows(Tensor src, Tensor row_of_pair, int k, int rows_out) -> Tensor");
@@ -610,6 +651,8 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("moe_topk_gate", moe_topk_gate);
+  m.impl("moe_plan", moe_plan);
   m.impl("grouped_gemm", grouped_gemm);
   m.impl("grouped_wgrad", grouped_wgrad);
   m.impl("moe_scatter_rows", moe_scatter_rows);

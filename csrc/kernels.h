@@ -102,6 +102,17 @@ void moe_gather_combine(const void* y, const long long* row_of_pair, const void*
 void moe_combine_bwd(const void* dout, const void* y, const long long* row_of_pair, const void* gates, void* dy,
                      float* dgate, long long npairs, int k, int C, hipStream_t st);
 
+// ---- MoE routing ---------------------------------------------------------------------------------
+// idx[t, j] / gates[t, j]: top-k of (logits + bias) per token (E <= 64, k <= 8) and the softmax of the
+// selected raw logits.
+void moe_topk_gate(const float* logits, const float* bias, long long* idx, float* gates, long long ntok, int E, int k,
+                   hipStream_t st);
+// Expert-sorted padded layout of the [npairs] expert ids (see csrc/moe_route.hip). hist is scratch of
+// moe_plan_blocks(npairs) * E ints; nrb = padded rows / 128.
+int moe_plan_blocks(long long npairs);
+void moe_plan(const long long* idx, long long npairs, int E, int nrb, int* hist, long long* row_of_pair,
+              int* block_group, long long* seg_start, long long* seg_rows, long long* counts, hipStream_t st);
+
 // ---- Column sums (bias gradients) ----------------------------------------------------------
 // out[N] (fp32, caller-zeroed) += column sums of x[M, N] (row stride ld elements, N % 8 == 0).
 void colsum(const void* x, float* out, long long M, int N, long long ld, bool is_bf16, hipStream_t st);

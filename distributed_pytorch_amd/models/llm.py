@@ -317,23 +317,19 @@ class MoE(nn.Module):
         cfg = self.config
         n_tokens = x_flat.shape[0]
         router_logits = ops.linear(x_flat, self.gate.weight).float()
-        if cfg.aux_free:
-            biased = router_logits + self.expert_bias.float()
-            _, topk_indices = torch.topk(biased, self.n_act_routed, dim=1)
-            topk_gates = F.softmax(torch.gather(router_logits, 1, topk_indices), dim=1)
-            with torch.no_grad():
-                fi = torch.bincount(topk_indices.flatten(), minlength=self.n_routed).float() / n_tokens
-                if self.training and not _in_recompute():
-                    self.expert_bias += (cfg.gamma * (1.0 / self.n_routed - fi)).to(self.expert_bias.dtype)
-            pi = F.softmax(router_logits, dim=1).mean(dim=0)
-            aux_loss = cfg.alpha * self.n_routed * torch.sum(pi * fi)
-        else:
-            pi = F.softmax(router_logits, dim=1).mean(dim=0)
-            topk_logits, topk_indices = torch.topk(router_logits, self.n_act_routed, dim=1)
-            with torch.no_grad():
-                fi = torch.bincount(topk_indices.flatten(), minlength=self.n_routed).float() / n_tokens
-            aux_loss = cfg.coeff * self.n_routed * torch.sum(pi * fi)
-            topk_gates = F.softmax(topk_logits, dim=1)
+        E, k = self.n_routed, self.n_act_routed
+        # top-k of (logits + selection bias), gates = softmax of the selected raw logits
+        topk_indices, topk_gates = ops.topk_gate(router_logits, self.expert_bias if cfg.aux_free else None, k)
+        self._layout = None
+        if self.dispatcher is None and x_flat.is_cuda:
+            self._layout = (topk_indices, ops.moe_plan(topk_indices, E))   # reused by routed_experts_local
+        with torch.no_grad():
+            counts = self._layout[1][5] if self._layout is not None else ops.expert_counts(topk_indices, E)
+            fi = counts.float() / n_tokens
+            if cfg.aux_free and self.training and not _in_recompute():
+                self.expert_bias += (cfg.gamma * (1.0 / E - fi)).to(self.expert_bias.dtype)
+        pi = F.softmax(router_logits, dim=1).mean(dim=0)
+        aux_loss = (cfg.alpha if cfg.aux_free else cfg.coeff) * E * torch.sum(pi * fi)
         return topk_indices, topk_gates.to(x_flat.dtype), aux_loss
 
     def routed_experts_local(self, x_flat, topk_indices, topk_gates):
@@ -348,11 +344,15 @@ class MoE(nn.Module):
             act = routed[0].expert.non_linearity
             if ops.grouped_supported(x_flat, fcs, projs, act):
                 # padded expert-sorted layout + grouped MFMA GEMMs: no host sync, no expert loop
-                return ops.grouped_experts(x_flat, topk_indices, topk_gates, fcs, projs, act)
+                layout = None
+                if getattr(self, "_layout", None) is not None and self._layout[0] is topk_indices:
+                    layout = self._layout[1]
+                self._layout = None
+                return ops.grouped_experts(x_flat, topk_indices, topk_gates, fcs, projs, act, layout)
         flat_e = topk_indices.reshape(-1)
         order = torch.argsort(flat_e, stable=True)
         tok = torch.div(order, k, rounding_mode="floor")
-        counts = torch.bincount(flat_e, minlength=self.n_routed).tolist()
+        counts = ops.expert_counts(flat_e, self.n_routed).tolist()
         xs = x_flat[tok]
         gs = topk_gates.reshape(-1)[order].unsqueeze(1)
         outs = []

@@ -30,17 +30,31 @@ def padded_rows(npairs: int, n_experts: int) -> int:
     return (npairs + n_experts * (BLOCK - 1) + BLOCK - 1) // BLOCK * BLOCK
 
 
+def expert_counts(topk_indices: torch.Tensor, n_experts: int) -> torch.Tensor:
+    """Pairs per expert, int64 [E]. (``torch.bincount`` reads the maximum back to the host on the GPU;
+    a scatter-add does not.)"""
+    flat = topk_indices.reshape(-1)
+    return torch.zeros(n_experts, dtype=torch.int64, device=flat.device).scatter_add_(
+        0, flat, torch.ones_like(flat))
+
+
 def plan(topk_indices: torch.Tensor, n_experts: int):
     """Device-side layout of the pairs (no host sync).
 
     -> row_of_pair [N*k] int64 (row of pair ``t*k + s`` in the padded buffer),
        block_group [rows/128] int32 (expert of each block, ``n_experts`` past the end),
-       seg_start, seg_rows [E] int64 (padded segment of each expert), rows (python int)."""
+       seg_start, seg_rows [E] int64 (padded segment of each expert), rows (python int),
+       counts [E] int64.
+    On the GPU this is the histogram / scan / placement kernel trio of ``csrc/moe_route.hip``; the
+    PyTorch statement below (one stable sort) defines the same layout."""
     flat_e = topk_indices.reshape(-1)
     npairs = flat_e.numel()
     rows = padded_rows(npairs, n_experts)
+    if use_hip(flat_e) and n_experts <= 64 and flat_e.dtype == torch.int64:
+        row_of_pair, block_group, seg_start, seg_rows, counts = ops().moe_plan(flat_e.contiguous(), n_experts, rows)
+        return row_of_pair, block_group, seg_start, seg_rows, rows, counts
     order = torch.argsort(flat_e, stable=True)
-    counts = torch.bincount(flat_e, minlength=n_experts)
+    counts = expert_counts(flat_e, n_experts)
     cstart = torch.cumsum(counts, 0) - counts
     seg_rows = (counts + (BLOCK - 1)) // BLOCK * BLOCK
     seg_end = torch.cumsum(seg_rows, 0)
@@ -51,7 +65,37 @@ def plan(topk_indices: torch.Tensor, n_experts: int):
     row_of_pair[order] = dest
     block_first = torch.arange(rows // BLOCK, device=flat_e.device) * BLOCK
     block_group = torch.searchsorted(seg_end, block_first, right=True).to(torch.int32)
-    return row_of_pair, block_group, seg_start.contiguous(), seg_rows.contiguous(), rows
+    return row_of_pair, block_group, seg_start.contiguous(), seg_rows.contiguous(), rows, counts
+
+
+class _TopkGateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, bias, k):
+        idx, gates = ops().moe_topk_gate(logits.contiguous(), bias, k)
+        ctx.save_for_backward(idx, gates)
+        ctx.n_experts = logits.shape[1]
+        ctx.mark_non_differentiable(idx)
+        return idx, gates
+
+    @staticmethod
+    def backward(ctx, _didx, dgates):
+        idx, gates = ctx.saved_tensors
+        dsel = gates * (dgates - (gates * dgates).sum(1, keepdim=True))    # softmax over the selected logits
+        dlogits = torch.zeros(idx.shape[0], ctx.n_experts, dtype=dgates.dtype, device=dgates.device)
+        dlogits.scatter_(1, idx, dsel)
+        return dlogits, None, None
+
+
+def topk_gate(router_logits: torch.Tensor, bias: torch.Tensor | None, k: int):
+    """(topk_indices int64 [N, k], gates fp32 [N, k]): top-k of ``router_logits + bias`` and the softmax of
+    the selected raw logits, in one kernel on the GPU (reference: single-gpu/model.py:447-472)."""
+    E = router_logits.shape[1]
+    if use_hip(router_logits) and router_logits.dtype == torch.float32 and E <= 64 and k <= min(8, E):
+        b = None if bias is None else bias.detach().float().contiguous()
+        return _TopkGateFn.apply(router_logits, b, k)
+    biased = router_logits if bias is None else router_logits + bias.float()
+    _, idx = torch.topk(biased, k, dim=1)
+    return idx, F.softmax(torch.gather(router_logits, 1, idx), dim=1)
 
 
 _PTR_TABLES: dict = {}
@@ -100,11 +144,11 @@ def _emit_wgrads(ws32, params, needs):
 
 class _GroupedExpertsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_flat, gates, topk_indices, act, n_experts, *weights):
-        E = n_experts
+    def forward(ctx, x_flat, gates, topk_indices, act, layout, *weights):
+        E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         k = topk_indices.shape[1]
-        row_of_pair, block_group, seg_start, seg_rows, rows = plan(topk_indices, E)
+        row_of_pair, block_group, seg_start, seg_rows, rows = (layout or plan(topk_indices, E))[:5]
         fc_ptrs, proj_ptrs = _ptr_table(fc), _ptr_table(proj)
         xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows)
         h = ops().grouped_gemm(xs, fc_ptrs, fc[0].shape[0], fc[0].shape[1], False, block_group)
@@ -162,10 +206,12 @@ def grouped_supported(x_flat, fc_weights, proj_weights, act: str) -> bool:
     return ok
 
 
-def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str) -> torch.Tensor:
+def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str, layout=None) -> torch.Tensor:
     """sum_s gate[t, s] * expert_{idx[t, s]}(x[t]) for bias-free two-layer experts
-    (``act`` = "gelu" or "swiglu") on the grouped HIP kernels."""
-    return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, len(fc_weights), *fc_weights, *proj_weights)
+    (``act`` = "gelu" or "swiglu") on the grouped HIP kernels. ``layout`` = a ``plan()`` result for
+    ``topk_indices`` if the caller already has one."""
+    assert len(fc_weights) == len(proj_weights)
+    return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, layout, *fc_weights, *proj_weights)
 
 
 def grouped_experts_eager(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str) -> torch.Tensor:

@@ -439,3 +439,48 @@ def test_grouped_experts_fwd_bwd(act, E, k, Ntok, C, U):
             continue
         assert rel_err(fh[e].grad, fr[e].grad) < 1.5e-2, e
         assert rel_err(ph[e].grad, pr[e].grad) < 1.5e-2, e
+
+
+@pytest.mark.parametrize("N,E,k,with_bias", [(4096, 8, 2, False), (1000, 64, 8, True), (77, 3, 1, True), (16384, 16, 4, False)])
+def test_moe_topk_gate_matches_torch(N, E, k, with_bias):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    logits = torch.randn(N, E, device=DEV) * 2
+    bias = torch.randn(E, device=DEV) if with_bias else None
+    dg = torch.randn(N, k, device=DEV)
+    lr = logits.clone().requires_grad_()
+    biased = lr if bias is None else lr + bias
+    _, idx_ref = torch.topk(biased, k, dim=1)
+    g_ref = F.softmax(torch.gather(lr, 1, idx_ref), dim=1)
+    g_ref.backward(dg)
+    lh = logits.clone().requires_grad_()
+    idx, g = ops.topk_gate(lh, bias, k)
+    g.backward(dg)
+    assert idx.dtype == torch.int64 and torch.equal(idx, idx_ref)     # random floats: no ties
+    assert torch.allclose(g, g_ref, atol=1e-6, rtol=1e-5)
+    assert torch.allclose(lh.grad, lr.grad, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("N,E,k", [(4096, 8, 2), (1000, 64, 8), (77, 3, 1), (65536, 8, 2), (5, 4, 2)])
+def test_moe_plan_matches_sort_based_layout(N, E, k):
+    """The histogram / scan / placement kernels produce exactly the stable-sort layout."""
+    from distributed_pytorch_amd.ops import moe
+    ops = _ops()
+    torch.manual_seed(0)
+    idx = torch.stack([torch.randperm(E, device=DEV)[:k] for _ in range(min(N, 512))])
+    idx = idx.repeat((N + idx.shape[0] - 1) // idx.shape[0], 1)[:N].contiguous()
+    if E > 2:
+        idx[idx == E - 1] = 0                  # leave one expert empty
+    rows = moe.padded_rows(N * k, E)
+    got = ops.moe_plan(idx.reshape(-1), E, rows)
+    import os
+    os.environ["DPA_FORCE_EAGER"] = "1"
+    try:
+        want = moe.plan(idx, E)
+    finally:
+        del os.environ["DPA_FORCE_EAGER"]
+    assert torch.equal(got[0], want[0])                       # row_of_pair
+    assert torch.equal(got[1], want[1])                       # block_group
+    assert torch.equal(got[2], want[2]) and torch.equal(got[3], want[3])
+    assert torch.equal(got[4], want[5])                       # counts
+    assert got[0].unique().numel() == N * k
