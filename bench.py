@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", type=str, default="ddp", choices=["single", "ddp", "zero1", "zero2", "fsdp", "fsdp_keep"])
+    ap.add_argument("--mode", type=str, default="ddp", choices=["single", "ddp", "zero1", "zero2", "fsdp", "fsdp_keep", "ep", "ep_fsdp"])
     ap.add_argument("--model", type=str, default="gpt2-124m", choices=sorted(PRESETS))
     ap.add_argument("--batch", type=int, default=64, help="micro-batch (sequences) per GPU")
     ap.add_argument("--seq", type=int, default=1024)

@@ -36,6 +36,7 @@ import torch.distributed as dist
 from .. import ops
 from . import comm
 from .ddp import DDPEngine
+from .fsdp import FSDPEngine
 from .flat import FlatAdamW, FlatGroup, plan_groups, unique_named_parameters
 
 
@@ -79,12 +80,12 @@ class ExpertParallelDispatcher:
         flat_e = topk_indices.reshape(-1)
         order = torch.argsort(flat_e, stable=True)
         tok = torch.div(order, k, rounding_mode="floor")
-        counts = torch.bincount(flat_e, minlength=moe.n_routed)            # rows per expert (global ids)
+        counts = ops.expert_counts(flat_e, moe.n_routed)                    # rows per expert (global ids)
         recv_counts = torch.empty_like(counts)
         comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
-        counts_h = counts.view(W, per).sum(1).tolist()                      # rows sent to each rank
         recv_mat = recv_counts.view(W, per)
-        recv_h = recv_mat.sum(1).tolist()                                   # rows received from each rank
+        # the one host read of the layer: rows sent to / received from each rank (the all-to-all splits)
+        counts_h, recv_h = torch.stack([counts.view(W, per).sum(1), recv_mat.sum(1)]).tolist()
         xs = x_flat[tok]
         recv = all_to_all_rows(xs, counts_h, recv_h, self.group)
         # regroup the received rows (ordered by source rank, then expert) by local expert
@@ -141,22 +142,7 @@ class EPEngine(DDPEngine):
         self.dispatcher = ExpertParallelDispatcher(self.group)
         cfg = self.module.config
         assert cfg.moe, "EPEngine needs an MoE model"
-        n_routed = cfg.n_exp - cfg.n_shared
-        lo, hi = self.dispatcher.local_expert_range(n_routed)
-        self._local_routed = (lo, hi)
-        local_named, self._dropped = [], []
-        for blk in self.module.transformer.h:
-            blk.moe.dispatcher = self.dispatcher
-        for n, p in unique_named_parameters(self.module):
-            ei = _expert_index(n)
-            if ei is not None and ei >= cfg.n_shared:
-                if lo <= ei - cfg.n_shared < hi:
-                    local_named.append((n, p))
-                else:
-                    p.requires_grad_(False)
-                    p.data = torch.empty(0, dtype=p.dtype, device=p.device)   # not owned here: free it
-                    self._dropped.append(n)
-        local_ids = {id(p) for _, p in local_named}
+        local_named = _drop_remote_experts(self, cfg)
         # dense parameters: bucketed + all-reduced (DDP); local experts: one group, never reduced
         for _, p in local_named:
             p.requires_grad_(False)
@@ -234,3 +220,125 @@ class EPEngine(DDPEngine):
         if name.endswith("c_fc.weight"):
             return ((2 if cfg.non_linearity.lower() == "swiglu" else 1) * cfg.up_dim, cfg.n_embd)
         return (cfg.n_embd, cfg.up_dim)
+
+
+def _drop_remote_experts(engine, cfg):
+    """Shared by the expert-parallel engines: install the dispatcher, free the routed experts that
+    other ranks own and return the (name, parameter) list of the local ones."""
+    n_routed = cfg.n_exp - cfg.n_shared
+    lo, hi = engine.dispatcher.local_expert_range(n_routed)
+    engine._local_routed = (lo, hi)
+    local_named, engine._dropped = [], []
+    for blk in engine.module.transformer.h:
+        blk.moe.dispatcher = engine.dispatcher
+    for n, p in unique_named_parameters(engine.module):
+        ei = _expert_index(n)
+        if ei is not None and ei >= cfg.n_shared:
+            if lo <= ei - cfg.n_shared < hi:
+                local_named.append((n, p))
+            else:
+                p.requires_grad_(False)
+                p.data = torch.empty(0, dtype=p.dtype, device=p.device)   # not owned here: free it
+                engine._dropped.append(n)
+    return local_named
+
+
+class EPFSDPEngine(FSDPEngine):
+    """Expert parallel for the routed experts + fully-sharded data parallel for everything else,
+    over the same process group: dense parameters (attention, norms, shared experts, router,
+    embeddings) live in per-block FSDP units that are all-gathered / reduce-scattered as in
+    ``FSDPEngine``; each rank's own routed experts stay resident, receive their tokens through
+    the all-to-all dispatcher and are never reduced (their gradient is already the global sum)."""
+
+    name = "ep_fsdp"
+
+    def _build_storage(self):
+        self.dispatcher = ExpertParallelDispatcher(self.group)
+        cfg = self.module.config
+        assert cfg.moe, "EPFSDPEngine needs an MoE model"
+        local_named = _drop_remote_experts(self, cfg)
+        for _, p in local_named:       # keep the experts out of the sharded units
+            p.requires_grad_(False)
+        super()._build_storage()
+        for _, p in local_named:
+            p.requires_grad_(True)
+        self.expert_group = self.expert_optim = None
+        if local_named:
+            g = FlatGroup(local_named, self.param_dtype, self.device, 8, self.weight_decay, "experts")
+            self.expert_group = g
+            self.expert_optim = FlatAdamW(g, 0, g.numel, betas=self.betas, eps=self.eps)
+            self.optims.append(self.expert_optim)    # checkpointed with the unit optimizers
+            g.drop_init()
+            if self.device.type == "cuda":
+                for s in g.slots:
+                    if s.param.dim() == 2:
+                        s.param._dpa_direct = True
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad()
+        if self.expert_group is not None:
+            self.expert_group.zero_grad()
+
+    def _compute_norm(self):
+        first = True
+        for u in self.units:
+            ops.sumsq(u.grad_shard, self._norm2, accumulate=not first)
+            first = False
+        if self.expert_group is not None:
+            ops.sumsq(self.expert_group.grad, self._norm2, accumulate=True)
+        comm.all_reduce(self._norm2, group=self.group)
+        self._have_norm = True
+
+    def _apply_updates(self, lr: float):
+        super()._apply_updates(lr)
+        if self.expert_group is not None:
+            g, o = self.expert_group, self.expert_optim
+            o.step(g.grad, g.data, lr, self.step_count, self._norm2, self._max_norm, self._grad_mul(), self._dyn)
+
+    def _refresh_params_from_master(self):
+        if self.expert_group is not None:
+            self.expert_group.data.copy_(self.expert_optim.master)
+        super()._refresh_params_from_master()
+
+    def state_dict(self, *args, **kwargs):
+        """Reference-schema fp32 state dict: dense tensors gathered from the shards, every routed
+        expert broadcast from its owner (collective: call on every rank)."""
+        by_param = {}
+        for gi, u in enumerate(self.units):
+            full = self._full_master(gi)
+            for s in u.slots:
+                by_param[id(s.param)] = full[s.offset:s.offset + s.numel].view(s.shape).clone()
+        if self.expert_group is not None:
+            for s in self.expert_group.slots:
+                by_param[id(s.param)] = self.expert_optim.master[s.offset:s.offset + s.numel].view(s.shape).clone()
+        cfg = self.module.config
+        per = (cfg.n_exp - cfg.n_shared) // self.world
+        sd = OrderedDict()
+        for k, p in self.module.named_parameters(remove_duplicate=False):
+            ei = _expert_index(k)
+            if ei is not None and ei >= cfg.n_shared:
+                owner = (ei - cfg.n_shared) // per
+                t = by_param[id(p)].to(self.device) if owner == self.rank else \
+                    torch.empty(EPEngine._expert_shape(self, k), device=self.device)
+                comm.broadcast(t, src=owner, group=self.group)
+                sd[k] = t
+            else:
+                sd[k] = by_param[id(p)]
+        for k, b in self.module.named_buffers():
+            mod_path, _, leaf = k.rpartition(".")
+            owner_mod = self.module.get_submodule(mod_path) if mod_path else self.module
+            if b is not None and leaf not in owner_mod._non_persistent_buffers_set:
+                sd[k] = b.detach().clone()
+        order = [k for k in self._state_dict_keys() if k in sd]
+        return OrderedDict((k, sd[k]) for k in order)
+
+    def load_model_state(self, sd: dict):
+        if self.expert_group is not None:
+            params = dict(self.module.named_parameters(remove_duplicate=False))
+            with torch.no_grad():
+                for s in self.expert_group.slots:
+                    key = next(k for k, p in params.items() if p is s.param and k in sd)
+                    src = sd[key].to(self.device).reshape(-1)
+                    self.expert_group.data[s.offset:s.offset + s.numel].copy_(src)
+                    self.expert_optim.master[s.offset:s.offset + s.numel].copy_(src.float())
+        super().load_model_state(sd)

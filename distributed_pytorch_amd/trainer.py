@@ -77,6 +77,12 @@ def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
     if mode in ("fsdp", "fsdp_keep"):
         from .parallel.fsdp import FSDPEngine
         return FSDPEngine(model, reshard_after_forward=(mode == "fsdp"), **kw)
+    if mode == "ep":
+        from .parallel.ep import EPEngine
+        return EPEngine(model, **kw)
+    if mode == "ep_fsdp":
+        from .parallel.ep import EPFSDPEngine
+        return EPFSDPEngine(model, **kw)
     raise ValueError(f"unknown parallel mode {mode!r}")
 
 

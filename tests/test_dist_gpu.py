@@ -72,19 +72,21 @@ def test_engine_through_rccl_matches_single(one_rank_group, mode):
         assert abs(a - b) < 2e-2 * abs(b) + 1e-3, (mode, got, ref)
 
 
-def test_expert_parallel_through_rccl(one_rank_group):
+@pytest.mark.parametrize("kind", ["ep", "ep_fsdp"])
+def test_expert_parallel_through_rccl(one_rank_group, kind):
     from distributed_pytorch_amd.config import LLMconfig
     from distributed_pytorch_amd.models.llm import LLM
     from distributed_pytorch_amd.parallel import comm
     from distributed_pytorch_amd.parallel.engine import Engine
-    from distributed_pytorch_amd.parallel.ep import EPEngine
+    from distributed_pytorch_amd.parallel.ep import EPEngine, EPFSDPEngine
     cfg = LLMconfig(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="mha",
                     pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2).finalize()
     torch.manual_seed(1)
     ref = _run(Engine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3), cfg)
     before = comm.STATS["all_to_all"]
     torch.manual_seed(1)
-    got = _run(EPEngine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3), cfg)
+    cls = EPEngine if kind == "ep" else EPFSDPEngine
+    got = _run(cls(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3), cfg)
     assert comm.STATS["all_to_all"] > before
     for a, b in zip(got, ref):
         assert abs(a - b) < 3e-2 * abs(b) + 1e-3, (got, ref)

@@ -84,3 +84,46 @@ def test_ep_matches_single(aux_free):
     assert list(got.keys()) == list(sd.keys())
     for k in sd:
         assert torch.allclose(got[k].float(), sd[k].float(), rtol=2e-4, atol=2e-5), f"{k} differs after the step"
+
+
+def _worker_fsdp(rank, world, aux_free):
+    from distributed_pytorch_amd.parallel.ep import EPFSDPEngine
+    model, cfg = _make(aux_free)
+    eng = EPFSDPEngine(model, weight_decay=0.0, dtype="fp32", eps=1e-5)
+    xb = _batch(cfg, 4)
+    x = xb[rank * 2:(rank + 1) * 2]
+    eng.zero_grad()
+    _, loss, _ = eng(x, x.roll(-1, 1))
+    loss.backward()
+    eng.finish_grad_sync()
+    egrads = {s.name: s.param.grad.clone() / world for s in eng.expert_group.slots}
+    eng.clip_grad_norm_(1.0)
+    eng.step(1e-2)
+    sd = eng.state_dict()
+    # a second step exercises the re-gather of the updated shards
+    eng.zero_grad()
+    _, loss2, _ = eng(x, x.roll(-1, 1))
+    loss2.backward()
+    eng.clip_grad_norm_(1.0)
+    eng.step(1e-2)
+    return loss.item(), egrads, ({k: v.clone() for k, v in sd.items()} if rank == 0 else None), loss2.item()
+
+
+@pytest.mark.parametrize("aux_free", [False, True])
+def test_ep_with_fsdp_dense_matches_single(aux_free):
+    """Routed experts expert-parallel, everything else fully sharded: same loss, expert gradients
+    and post-step weights as the single-process model."""
+    losses, grads, sd = _single(aux_free)
+    outs = run_distributed(_worker_fsdp, 2, aux_free)
+    seen = set()
+    for r in range(2):
+        assert abs(outs[r][0] - losses[r]) < 1e-5
+        for n, g in outs[r][1].items():
+            assert torch.allclose(g, grads[n], rtol=1e-4, atol=1e-6), f"rank {r}: grad of {n} differs"
+            seen.add(n)
+        assert outs[r][3] < outs[r][0]          # the step reduced the loss on the same batch
+    assert seen == {n for n in grads if ".moe.experts." in n and int(n.split(".experts.")[1].split(".")[0]) >= 1}
+    got = outs[0][2]
+    assert list(got.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.allclose(got[k].float(), sd[k].float(), rtol=2e-4, atol=2e-5), f"{k} differs after the step"
