@@ -606,9 +606,30 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> moe_plan(const Tensor& idx, i
   return {row_of_pair, block_group, seg_start, seg_rows, counts};
 }
 
+// (fp32 slabs [splits, N, K] of dy^T x, fp32 bias gradient [N]): the column sums of dy come out of the
+// weight-gradient kernel itself when the shape runs on the 256 x 256 kernel, else from the column-sum kernel.
+std::tuple<Tensor, Tensor> wgrad2_slabs_bias(const Tensor& dy, const Tensor& x) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1);
+  TORCH_CHECK(x.size(0) == M && dpa::wgrad2_ok((int)M, (int)N, (int)K), "wgrad2: unsupported shape ", M, "x", N, "x", K);
+  const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
+  Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
+  if (dpa::wgrad2_fuses_bias((int)M, (int)N, (int)K)) {
+    Tensor bslabs = at::empty({splits, N}, dy.options().dtype(at::kFloat));
+    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                     x.stride(0), splits, cur_stream(), bslabs.data_ptr<float>());
+    return {slabs, splits == 1 ? bslabs.view({N}) : bslabs.sum(0)};
+  }
+  dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                   x.stride(0), splits, cur_stream());
+  return {slabs, colsum(dy)};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dpa, m) {
+  m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
   m.def("moe_topk_gate(Tensor logits, Tensor? bias, int k) -> (Tensor, Tensor)");
   m.def("moe_plan(Tensor idx, int n_experts, int rows) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("grouped_gemm(Tensor a, Tensor w_ptrs, int w_rows, int w_cols, bool w_is_kn, Tensor block_group) -> Tensor");
@@ -651,6 +672,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);
   m.impl("moe_topk_gate", moe_topk_gate);
   m.impl("moe_plan", moe_plan);
   m.impl("grouped_gemm", grouped_gemm);

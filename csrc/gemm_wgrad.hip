@@ -302,10 +302,15 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
 // LDS ceiling from about half to about three quarters of the MFMA rate. One workgroup per CU;
 // two 64 KiB stages, filled by LDS-DMA issued from inline assembly (see dma_subtile_asm) so that
 // the transfer of tile t+1 stays in flight during the MFMAs of tile t.
-template <bool ACCUM>
+//
+// BIAS: the workgroups of the first K-tile column also sum their dY fragments over the tokens on the
+// otherwise idle VALU (each lane adds the 8 tokens of its column), giving the bias gradient
+// per split without a second pass over dY.
+template <bool ACCUM, bool BIAS>
 __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                        float* __restrict__ slabs, int M, int N, int K,
-                                                        long long ldy, long long ldx, int splits, int mper) {
+                                                        float* __restrict__ slabs, float* __restrict__ bias_slabs,
+                                                        int M, int N, int K, long long ldy, long long ldx,
+                                                        int splits, int mper) {
   constexpr int SUB = 64 * 128 * 2;  // 16 KiB
   constexpr int STAGE = 4 * SUB;     // 64 KiB: two dY sub-tiles + two X sub-tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -328,6 +333,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = BIAS && tk == 0 && wk == 0;
 
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
   auto issue = [&](int t, int stage) {
@@ -359,6 +366,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 v = __builtin_bit_cast(u32x4, a[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[i] += lo_bf16(v[e]) + hi_bf16(v[e]);
+        }
+      }
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (hh == 0) bias_slabs[(long long)split * N + n0 + 128 * wn + 32 * i + (lane & 31)] = tot;
     }
   }
 
@@ -459,25 +481,31 @@ int wgrad2_splits(int M, int N, int K) {
 // over all tokens that ADDS into ws[N*K] (accumulation across calls, e.g. lm_head row chunks).
 void wgrad2_set_stages(int s) { g_wgrad2_stages = s; }
 
+bool wgrad2_fuses_bias(int M, int N, int K) { return use_wgrad3(M, N, K); }
+
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
-                 int splits, hipStream_t st) {
+                 int splits, hipStream_t st, float* bias_slabs) {
   if (M == 0) return;
   const int sp = splits > 0 ? splits : 1;
   int mper = (M / 64 + sp - 1) / sp * 64;
   if (use_wgrad3(M, N, K)) {
     static bool attr3 = false;
     if (!attr3) {
-      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       attr3 = true;
     }
     const dim3 grid3((N / 256) * (K / 256) * sp), block3(256);
-    if (splits > 0)
-      hipLaunchKernelGGL((wgrad3_kernel<false>), grid3, block3, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M,
-                         N, K, ldy, ldx, sp, mper);
-    else
-      hipLaunchKernelGGL((wgrad3_kernel<true>), grid3, block3, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M,
-                         N, K, ldy, ldx, sp, mper);
+#define DPA_W3(ACC, BI)                                                                                          \
+  hipLaunchKernelGGL((wgrad3_kernel<ACC, BI>), grid3, block3, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws, \
+                     bias_slabs, M, N, K, ldy, ldx, sp, mper)
+    if (splits > 0) {
+      if (bias_slabs != nullptr) DPA_W3(false, true); else DPA_W3(false, false);
+    } else {
+      DPA_W3(true, false);
+    }
+#undef DPA_W3
     return;
   }
   const dim3 grid(((N + kW2N - 1) / kW2N) * (K / kW2K) * sp), block(256);

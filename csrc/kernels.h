@@ -78,8 +78,11 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 bool wgrad2_ok(int M, int N, int K);
 int wgrad2_splits(int M, int N, int K);
 void wgrad2_set_stages(int s);
+// bias_slabs (optional, only when wgrad2_fuses_bias(M, N, K) and splits > 0): fp32 [splits, N] receiving the
+// per-split column sums of dy (the bias gradient), produced inside the same kernel.
+bool wgrad2_fuses_bias(int M, int N, int K);
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
-                 int splits, hipStream_t st);
+                 int splits, hipStream_t st, float* bias_slabs = nullptr);
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
                   hipStream_t st);
 

@@ -44,8 +44,12 @@ def weight_grad(dy2: torch.Tensor, x2: torch.Tensor, want_bias: bool, version: i
     """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16."""
     N, K = dy2.shape[1], x2.shape[1]
     if version != 1 and wgrad2_supported(dy2, x2):
-        dw = ops().wgrad2(dy2, x2)
-        return dw, (bias_grad(dy2) if want_bias else None)
+        if want_bias:
+            slabs, db = ops().wgrad2_slabs_bias(dy2, x2)   # bias sums come out of the same kernel
+            dw = torch.empty(N, K, dtype=dy2.dtype, device=dy2.device)
+            ops().ws_to(slabs, dw, False)
+            return dw, db.to(dy2.dtype)
+        return ops().wgrad2(dy2, x2), None
     ws = torch.zeros(N, K, dtype=torch.float32, device=dy2.device)
     bws = torch.zeros(N, dtype=torch.float32, device=dy2.device) if want_bias else None
     ops().wgrad_into(dy2, x2, ws, bws)
@@ -91,9 +95,12 @@ class _LinearFn(torch.autograd.Function):
             # of convert + autograd's accumulate). Returning None for dw still runs the parameter's
             # AccumulateGrad node, so post-accumulate hooks (bucket / unit accounting of the
             # engines) fire exactly as they do for an autograd-accumulated gradient.
-            ops().ws_to(ops().wgrad2_slabs(dy2, x2), target, True)
             if need_b:
-                db = bias_grad(dy2)
+                slabs, dbf = ops().wgrad2_slabs_bias(dy2, x2)
+                db = dbf.to(dy2.dtype)
+            else:
+                slabs = ops().wgrad2_slabs(dy2, x2)
+            ops().ws_to(slabs, target, True)
         elif ctx.needs_input_grad[1]:
             if wgrad2_supported(dy2, x2) or wgrad_supported(dy2, x2):
                 dw, db = weight_grad(dy2, x2, need_b)

@@ -484,3 +484,17 @@ def test_moe_plan_matches_sort_based_layout(N, E, k):
     assert torch.equal(got[2], want[2]) and torch.equal(got[3], want[3])
     assert torch.equal(got[4], want[5])                       # counts
     assert got[0].unique().numel() == N * k
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 2304, 768), (4096, 768, 768), (1024, 256, 256), (2048, 200, 256)])
+def test_wgrad_with_fused_bias_sums(M, N, K):
+    """Weight gradient and bias gradient from one op: column sums come out of the 256x256 kernel
+    where it applies (first three shapes) and from the column-sum kernel otherwise."""
+    ops = _ops()
+    torch.manual_seed(13)
+    dy = (torch.randn(M, N, device=DEV) + 0.1).to(torch.bfloat16)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    slabs, db = ops.wgrad2_slabs_bias(dy, x)
+    assert db.dtype == torch.float32 and db.shape == (N,)
+    assert rel_err(slabs.sum(0), dy.float().t() @ x.float()) < 1e-5
+    assert rel_err(db, dy.float().sum(0)) < 1e-5
