@@ -125,6 +125,9 @@ template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
   u32x4 v;
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  // Makes the packed value opaque to the optimizer at this point, so an unpack that follows inside a
+  // loop is not hoisted out of it (which would bring the fp32 copy back into live registers).
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v)); }
   __device__ __forceinline__ void get(float (&o)[8]) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -136,6 +139,7 @@ template <> struct Vec8<bf16_t> {
 template <> struct Vec8<float> {
   float f[8];
   __device__ __forceinline__ void load(const float* p) { load8(p, f); }
+  __device__ __forceinline__ void pin() {}
   __device__ __forceinline__ void get(float (&o)[8]) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f[i];

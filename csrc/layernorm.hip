@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // registers; the four waves of a block are combined through LDS and written as one partial
 // row per block. A second kernel folds the partial rows.
 template <typename T, int NCH, int LPR>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (NCH * (int)sizeof(T) <= 6) ? 3 : 1) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ part_dw,
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & (LPR - 1), wid = threadIdx.x >> 6, sub = (threadIdx.x & 63) / LPR;
   const int nchunk = C >> 3;
-  float aw[NCH][8], ab[NCH][8], wv[NCH][8];
+  float aw[NCH][8], ab[NCH][8];
+  Vec8<T> wv[NCH];   // gamma stays in its storage format: with bf16 that keeps the kernel at 3 waves per SIMD
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * LPR;
@@ -108,9 +109,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int j = 0; j < 8; ++j) {
       aw[i][j] = 0.f;
       ab[i][j] = 0.f;
-      wv[i][j] = 0.f;
     }
-    if (c < nchunk) load8(w + c * 8, wv[i]);
+    wv[i].load(w + (c < nchunk ? c : 0) * 8);
   }
   for (int row = (blockIdx.x * 4 + wid) * RPW + sub; row < rows; row += gridDim.x * 4 * RPW) {
     const float mu = mean[row], rs = rstd[row];
@@ -128,13 +128,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * LPR;
       if (c < nchunk) {
-        float d[8], xv[8];
+        float d[8], xv[8], wf[8];
         load8(dy + (size_t)row * C + c * 8, d);
         load8(x + (size_t)row * C + c * 8, xv);
+        wv[i].pin();
+        wv[i].get(wf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xh[i][j] = (xv[j] - mu) * rs;
-          g[i][j] = d[j] * wv[i][j];
+          g[i][j] = d[j] * wf[j];
           s1 += g[i][j];
           s2 += g[i][j] * xh[i][j];
           aw[i][j] += d[j] * xh[i][j];
