@@ -5,19 +5,20 @@
 // matrix, and BOTH operands are "contraction-strided" (row-major activations, contraction
 // down the rows). Library kernels launch a few dozen workgroups for it and crawl.
 //
-// Design:
-//  * one workgroup = one 128x128 output tile x one slice of the token range (split-M): the grid
-//    is (N/128) * (K/128) * splits workgroups, sized to >= 2 per CU;
-//  * dY and X tiles of 64 tokens x 128 columns are staged row-major into LDS exactly as they
-//    sit in memory (16-byte loads, XOR-swizzled chunks, double-buffered, loads of tile t+1 in
-//    flight during the MFMAs of tile t); both MFMA operands are fetched with the transposed
-//    LDS read (ds_read_b64_tr_b16), so no transposed copy of any activation is ever made;
-//  * each of the 4 waves owns a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators;
-//  * partial tiles are accumulated in an fp32 workspace (plain read-modify-write when the
-//    tile has a single owner, float atomics — whole 128-byte row segments per instruction —
-//    when the token range is split), and a small pass converts / adds into the bf16 gradient;
-//  * the bias gradient (column sums of dY) is folded into the staging pass of the workgroups
-//    of the first K-tile column: the values are already in registers on their way to LDS.
+// Common design: split-M (the token range is divided over workgroups so that a small output
+// matrix still fills 256 CUs), dY and X tiles staged row-major into LDS exactly as they sit in
+// memory under an XOR swizzle, both MFMA operands fetched with the transposed LDS read
+// (ds_read_b64_tr_b16) so no transposed copy of an activation is ever made, fp32 partial results
+// per split folded into the bf16 (or fp32) gradient by a small finishing pass.
+//
+// Three kernels, fastest applicable one first:
+//  * wgrad3_kernel: 256x256 output tile, 4 waves of 128x128 (accumulators in AGPRs), one workgroup
+//    per CU, two 64 KiB LDS stages filled by LDS-DMA from inline assembly; per-split fp32 slabs;
+//    optional bias gradient from the dY fragments. Needs N % 256 == 0 and K % 256 == 0.
+//  * wgrad2_kernel: 128x256 tile, 4 waves of 128x64, single 48 KiB LDS buffer filled by LDS-DMA,
+//    two workgroups per CU hide each other's transfer latency. Needs K % 256 == 0, M % 64 == 0.
+//  * wgrad_kernel: 128x128 tile, register-staged double buffer, fp32 workspace with float atomics
+//    across splits, bias gradient folded into the staging pass. Needs N, K % 128 == 0.
 //
 // Replaces the dW GEMMs that `nn.Linear`'s backward issues implicitly in the reference
 // (reference: single-gpu/model.py:112-114,373-384,559).
@@ -184,7 +185,7 @@ __device__ __forceinline__ void dma_subtile_asm(const bf16_t* g, long long ld, i
   }
 }
 
-template <bool ACCUM, int STAGES>
+template <bool ACCUM>
 __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                      float* __restrict__ slabs, int M, int N, int K, long long ldy,
                                                      long long ldx, int splits, int mper) {
@@ -234,46 +235,11 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
     }
   };
 
-  if (STAGES == 3) {
-    // Three-stage ring, one workgroup per CU: the DMAs of tiles t+1 and t+2 stay in flight during
-    // the MFMAs of tile t. Per tile: wait until all but this wave's newest 12 DMAs (tile t+1)
-    // have landed, one barrier (publishes tile t, and proves every wave is done with tile t-1
-    // whose stage is refilled next), issue tile t+2, compute tile t.
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    auto issue_asm = [&](int t, int stage) {
-      const long long m = m_begin + (long long)t * 64;
-      const unsigned base = lds0 + stage * STAGE;
-      dma_subtile_asm(dy + m * ldy + n0, ldy, N - n0, base, wave, lane);
-      dma_subtile_asm(x + m * ldx + k0, ldx, K - k0, base + SUB, wave, lane);
-      dma_subtile_asm(x + m * ldx + k0 + 128, ldx, K - k0 - 128, base + 2 * SUB, wave, lane);
-    };
-    if (ntiles > 0) issue_asm(0, 0);
-    if (ntiles > 1) issue_asm(1, 1);
-    int stage = 0;
-    for (int t = 0; t < ntiles; ++t) {
-      if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (t + 2 < ntiles) issue_asm(t + 2, stage == 0 ? 2 : stage - 1);
-      compute(stage);
-      stage = (stage == 2) ? 0 : stage + 1;
-    }
-  } else if (STAGES == 1) {
-    for (int t = 0; t < ntiles; ++t) {
-      __syncthreads();          // everybody is done reading the previous tile
-      issue(t, 0);
-      __syncthreads();          // waits for this wave's DMA (vmcnt) and for everybody else's
-      compute(0);
-    }
-  } else {
-    // Double-buffered: the DMA of tile t+1 is in flight during the MFMAs of tile t; one barrier
-    // per tile (it drains this wave's DMA, then orders it against everybody's reads).
-    if (ntiles > 0) issue(0, 0);
-    for (int t = 0; t < ntiles; ++t) {
-      __syncthreads();          // tile t has landed; all waves finished computing tile t-1
-      if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
-      compute(t & 1);
-    }
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();          // everybody is done reading the previous tile
+    issue(t, 0);
+    __syncthreads();          // waits for this wave's DMA (vmcnt) and for everybody else's
+    compute(0);
   }
 
   float* out = slabs + (ACCUM ? 0 : (long long)split * N * K);
@@ -454,7 +420,7 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 
 bool wgrad2_ok(int M, int N, int K) { return M % 64 == 0 && M >= 64 && N % 8 == 0 && K % kW2K == 0; }
 
-int g_wgrad2_stages = 4;   // 4 = 256x256 kernel where the shape allows (else single buffer); 1/2/3 = wgrad2_kernel variants (benchmarks)
+int g_wgrad2_stages = 4;   // 4 = 256x256 kernel where the shape allows, else (and with 1) the 128x256 kernel (benchmark knob)
 
 static bool use_wgrad3(int M, int N, int K) {
   return g_wgrad2_stages == 4 && N % 256 == 0 && K % 256 == 0 && M >= 1024;
@@ -469,7 +435,7 @@ int wgrad2_splits(int M, int N, int K) {
     return s3 < 1 ? 1 : s3;
   }
   const int tiles = ((N + kW2N - 1) / kW2N) * (K / kW2K);
-  int s = (g_wgrad2_stages == 1 ? 512 : 256) / tiles;   // one round of the workgroups that fit per CU
+  int s = 512 / tiles;   // one round of the workgroups that fit (two per CU)
   const int max_s = M / 256;           // at least 4 LDS tiles per workgroup
   if (s > max_s) s = max_s;
   if (s > 64) s = 64;
@@ -509,25 +475,13 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
     return;
   }
   const dim3 grid(((N + kW2N - 1) / kW2N) * (K / kW2K) * sp), block(256);
-  const int stages = g_wgrad2_stages == 4 ? 1 : g_wgrad2_stages;
-  const size_t lds = (size_t)stages * 3 * 64 * 128 * 2;  // 48 KiB per stage
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-    (void)hipFuncSetAttribute((const void*)wgrad2_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-    attr = true;
-  }
-#define DPA_W2(ACC, ST)                                                                                        \
-  hipLaunchKernelGGL((wgrad2_kernel<ACC, ST>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, \
-                     K, ldy, ldx, sp, mper)
-  if (splits > 0) {
-    if (stages == 3) DPA_W2(false, 3); else if (stages == 2) DPA_W2(false, 2); else DPA_W2(false, 1);
-  } else {
-    if (stages == 3) DPA_W2(true, 3); else if (stages == 2) DPA_W2(true, 2); else DPA_W2(true, 1);
-  }
-#undef DPA_W2
+  const size_t lds = (size_t)3 * 64 * 128 * 2;  // 48 KiB: two workgroups per CU hide each other's DMA latency
+  if (splits > 0)
+    hipLaunchKernelGGL((wgrad2_kernel<false>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
+                       ldy, ldx, sp, mper);
+  else
+    hipLaunchKernelGGL((wgrad2_kernel<true>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
+                       ldy, ldx, sp, mper);
 }
 
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
