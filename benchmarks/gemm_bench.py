@@ -26,14 +26,14 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (50304, 768)]:
     ref = dy.float().t() @ x.float()
     for st in (1, 4):
         torch.ops.dpa.wgrad2_set_stages(st)
-        err = ((ops.weight_grad(dy, x, False)[0].float() - ref).norm() / ref.norm()).item()
+        err = ((ops.weight_grad(dy, x, False, version=2)[0].float() - ref).norm() / ref.norm()).item()
         assert err < 5e-3, (st, err)
     del ref
     t_lib = timeit(lambda: torch.mm(dy.t(), x))
     t_v1 = timeit(lambda: ops.weight_grad(dy, x, False, version=1))
     torch.ops.dpa.wgrad2_set_stages(1)
-    t_v2 = timeit(lambda: ops.weight_grad(dy, x, False))
+    t_v2 = timeit(lambda: ops.weight_grad(dy, x, False, version=2))
     torch.ops.dpa.wgrad2_set_stages(4)
-    t_v4 = timeit(lambda: ops.weight_grad(dy, x, False))
+    t_v4 = timeit(lambda: ops.weight_grad(dy, x, False, version=2))
     print(f"dW[{N},{K}] M={Mx}: library {t_lib*1e3:8.1f} us ({fl/t_lib/1e9:7.1f} TF)   v1 {t_v1*1e3:8.1f} us ({fl/t_v1/1e9:7.1f} TF)"
           f"   v2 {t_v2*1e3:8.1f} us ({fl/t_v2/1e9:7.1f} TF)   256x256 {t_v4*1e3:8.1f} us ({fl/t_v4/1e9:7.1f} TF)", flush=True)

@@ -32,6 +32,17 @@ def wgrad2_supported(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
 
 
+# Output sizes from which the library's split-K kernels overtake the hand-written weight-gradient
+# kernels (measured on MI355X, benchmarks/wgrad_shapes_bench.py: own kernels win up to 4.2 M output
+# elements, the library from 12.6 M; a 256x256 tiling of a large output no longer divides evenly
+# over 256 CUs and the split-M advantage is gone).
+LIBRARY_WGRAD_MIN_OUT = 8 * 1024 * 1024
+
+
+def _library_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
+    return dy2.shape[1] * x2.shape[1] >= LIBRARY_WGRAD_MIN_OUT
+
+
 def bias_grad(dy2: torch.Tensor) -> torch.Tensor:
     """Column sums of dy2 [M, N] in its own dtype (fp32 accumulation on the GPU kernel)."""
     if (dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float32) and dy2.stride(1) == 1
@@ -41,8 +52,11 @@ def bias_grad(dy2: torch.Tensor) -> torch.Tensor:
 
 
 def weight_grad(dy2: torch.Tensor, x2: torch.Tensor, want_bias: bool, version: int = 0):
-    """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16."""
+    """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16. ``version``: 0 = fastest path for
+    the shape (library for very large outputs), 1 = register-staged kernel, 2 = LDS-DMA kernels."""
     N, K = dy2.shape[1], x2.shape[1]
+    if version == 0 and _library_wgrad(dy2, x2):
+        return torch.mm(dy2.t(), x2), (bias_grad(dy2) if want_bias else None)
     if version != 1 and wgrad2_supported(dy2, x2):
         if want_bias:
             slabs, db = ops().wgrad2_slabs_bias(dy2, x2)   # bias sums come out of the same kernel
@@ -67,7 +81,7 @@ def _direct_target(w_param, dy2, x2):
     if g is None or g.dtype not in (torch.bfloat16, torch.float32) or not g.is_contiguous() \
             or g.data_ptr() % 16 != 0 or g.numel() % 8 != 0:
         return None
-    return g if wgrad2_supported(dy2, x2) else None
+    return g if (wgrad2_supported(dy2, x2) and not _library_wgrad(dy2, x2)) else None
 
 
 class _LinearFn(torch.autograd.Function):
