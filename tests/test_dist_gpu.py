@@ -92,6 +92,27 @@ def test_expert_parallel_through_rccl(one_rank_group, kind):
         assert abs(a - b) < 3e-2 * abs(b) + 1e-3, (got, ref)
 
 
+def test_vocab_parallel_cross_entropy_hip_halves(one_rank_group):
+    """STATS + all-reduce + GRAD kernels (the two halves of vocab-parallel cross-entropy) against
+    F.cross_entropy, with a vocabulary offset so that some targets fall outside the local shard."""
+    import torch.nn.functional as F
+    from distributed_pytorch_amd.ops import vocab_parallel_cross_entropy
+    torch.manual_seed(0)
+    N, V = 512, 4096
+    logits = (torch.randn(N, V, device="cuda") * 3).to(torch.bfloat16)
+    targets = torch.randint(0, V, (N,), device="cuda")
+    targets[::7] = -1
+    ref_in = logits.float().requires_grad_()
+    ref = F.cross_entropy(ref_in, targets, ignore_index=-1)
+    ref.backward()
+    local = logits.clone().requires_grad_()
+    loss = vocab_parallel_cross_entropy(local, targets, 0)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 2e-3 * abs(ref.item())
+    err = (local.grad.float() - ref_in.grad).norm() / ref_in.grad.norm()
+    assert err.item() < 1e-2
+
+
 @pytest.mark.parametrize("mode", ["ddp", "fsdp"])
 def test_bench_launch_line_prints_one_json_line(mode):
     """The multi-GPU launch line with one rank: stdout is exactly the JSON result."""

@@ -115,3 +115,29 @@ def test_zero2_uses_reduce_scatter_and_all_gather_only():
     assert st["reduce_scatter"] == out["total"], "every gradient byte goes through reduce-scatter exactly once"
     assert st["all_gather"] == out["total"], "every parameter byte comes back through all-gather exactly once"
     assert st["all_reduce"] <= 64, "only the scalar norm is all-reduced"
+
+
+def _vp_worker(rank, world):
+    import torch.nn.functional as F
+    from distributed_pytorch_amd.ops import vocab_parallel_cross_entropy
+    torch.manual_seed(0)
+    N, V = 24, 40
+    logits = torch.randn(N, V) * 3
+    targets = torch.randint(0, V, (N,))
+    targets[::5] = -1                                    # ignored rows
+    ref_in = logits.clone().requires_grad_()
+    ref = F.cross_entropy(ref_in, targets, ignore_index=-1)
+    ref.backward()
+    per = V // world
+    local = logits[:, rank * per:(rank + 1) * per].clone().requires_grad_()
+    loss = vocab_parallel_cross_entropy(local, targets, rank * per)
+    loss.backward()
+    return loss.item(), ref.item(), (local.grad - ref_in.grad[:, rank * per:(rank + 1) * per]).abs().max().item()
+
+
+def test_vocab_parallel_cross_entropy_matches_full():
+    """Logits sharded along the vocabulary over 2 ranks: same loss and gradient as the full
+    cross-entropy (max / sum-exp / target logit combined with two small all-reduces)."""
+    for loss, ref, gerr in run_distributed(_vp_worker, 2):
+        assert abs(loss - ref) < 1e-5
+        assert gerr < 1e-6
