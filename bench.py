@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--bucket_mb", type=float, default=48.0)
     ap.add_argument("--act_recomp", action="store_true")
+    ap.add_argument("--act_recomp_scope", type=str, default="attn", choices=["attn", "block"])
     ap.add_argument("--hip_graph", action="store_true", help="replay the optimizer step from one hipGraph (1 GPU)")
     args = ap.parse_args()
 
@@ -69,6 +70,7 @@ def main():
     mc = LLMconfig(**{**LLMconfig().to_dict(), **PRESETS[args.model]})
     mc.block_size = args.seq
     mc.act_recomp = args.act_recomp
+    mc.act_recomp_scope = args.act_recomp_scope
     mc.finalize()
     B, T = args.batch, args.seq
     global_batch = B * world * args.accum

@@ -51,6 +51,7 @@ class LLMconfig:
     kv_latent_dim: Optional[int] = 32
     rope_head_dim: Optional[int] = 16
     act_recomp: bool = False
+    act_recomp_scope: str = "attn"      # "attn": recompute attention only; "block": recompute whole blocks
 
     def finalize(self) -> "LLMconfig":
         """Apply the post-parse fix-ups of the reference (single-gpu/train.py:198-206)."""
@@ -184,6 +185,7 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--warmup_steps", type=int, default=tc.warmup_steps)
     p.add_argument("--grad_clip", type=float, default=tc.grad_clip)
     p.add_argument("--act_recomp", action="store_true")
+    p.add_argument("--act_recomp_scope", type=str, default=mc.act_recomp_scope, choices=["attn", "block"])
     p.add_argument("--vocab_size", type=int, default=mc.vocab_size)
     p.add_argument("--block_size", type=int, default=mc.block_size)
     p.add_argument("--n_embd", type=int, default=mc.n_embd)

@@ -392,7 +392,8 @@ class Block(nn.Module):
     def __init__(self, config: LLMconfig):
         super().__init__()
         self.is_moe = config.moe
-        self.act_recomp = config.act_recomp
+        # attention-only recomputation lives here; whole-block recomputation in LLM.forward
+        self.act_recomp = config.act_recomp and getattr(config, "act_recomp_scope", "attn") == "attn"
         self.attn = Attention(config)
         self.ln1 = nn.LayerNorm(config.n_embd)
         self.ln2 = nn.LayerNorm(config.n_embd)
@@ -554,8 +555,17 @@ class LLM(nn.Module):
         new_caches = []
         total_aux = 0.0
         delta = None
+        # Whole-block recomputation (reference: single-gpu/model.py:677-680): only the block inputs are
+        # kept, the block runs again in backward (non-reentrant, so hooks and direct gradient
+        # accumulation behave as in a plain backward).
+        block_ckpt = (cfg.act_recomp and getattr(cfg, "act_recomp_scope", "attn") == "block" and self.training
+                      and torch.is_grad_enabled() and all(c is None for c in kv_caches))
         for i, block in enumerate(self.transformer.h):
-            x, delta, cache, aux = block(x, delta, rope, kv_caches[i], self.VAL_RUN)
+            if block_ckpt:
+                x, delta, cache, aux = checkpoint(block, x, delta, rope, None, self.VAL_RUN, use_reentrant=False,
+                                                  context_fn=_ckpt_contexts)
+            else:
+                x, delta, cache, aux = block(x, delta, rope, kv_caches[i], self.VAL_RUN)
             new_caches.append(cache)
             total_aux = total_aux + aux
         ln_f = self.transformer.ln_f

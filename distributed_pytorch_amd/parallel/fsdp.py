@@ -33,6 +33,7 @@ from collections import deque
 import torch
 
 from .. import ops
+from ..models.llm import _in_recompute
 from . import comm
 from .engine import Engine
 from .flat import FlatAdamW, FlatGroup, plan_groups
@@ -62,6 +63,10 @@ class FSDPUnit(FlatGroup):
 
     # -- parameters -------------------------------------------------------------------------
     def release_params(self):
+        if self.gather_work is not None:     # a prefetch nobody consumed: retire it before freeing
+            self.gather_work.wait()
+            self.gather_work = None
+            self.gathered = True
         if self.gathered:
             self.data.untyped_storage().resize_(0)
             self.gathered = False
@@ -143,7 +148,7 @@ class FSDPEngine(Engine):
     def _make_pre_fwd(self, i):
         def hook(module, args):
             n = len(self.block_units)
-            if i + 1 < n:
+            if i + 1 < n and not _in_recompute():   # (a recomputed block is followed by block i-1, not i+1)
                 self.block_units[i + 1].begin_gather(self.group)   # prefetch the next unit first
             self.block_units[i].wait_gather(self.group)
         return hook
@@ -152,6 +157,8 @@ class FSDPEngine(Engine):
         def hook(module, args, output):
             # the last unit also holds the final LayerNorm and is the first one backward needs
             last = i == len(self.block_units) - 1
+            if _in_recompute():      # the block's own backward follows immediately: keep it gathered
+                return
             if self.reshard_after_forward and not last:
                 self.block_units[i].release_params()
         return hook

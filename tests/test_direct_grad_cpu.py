@@ -1,6 +1,7 @@
 """The direct gradient-accumulation protocol (the weight-gradient kernel writes into the engine's
 flat gradient buffer and returns no gradient to autograd; the parameter's post-accumulate hook
-still fires and drives the engines' bucket / unit accounting) exercised on the CPU: the two GPU ops are replaced by torch equivalents, everything else — engines, hooks,
+still fires and drives the engines' bucket / unit accounting) exercised on the CPU: the GPU ops
+are replaced by torch equivalents, everything else — engines, hooks,
 FSDP release / re-materialise of gradient storage — is the production code."""
 import types
 
@@ -19,6 +20,10 @@ class _FakeHip:
     @staticmethod
     def wgrad2_slabs(dy2, x2):
         return (dy2.float().t() @ x2.float()).unsqueeze(0)
+
+    @staticmethod
+    def wgrad2_slabs_bias(dy2, x2):
+        return (dy2.float().t() @ x2.float()).unsqueeze(0), dy2.float().sum(0)
 
     @staticmethod
     def wgrad2(dy2, x2):
@@ -83,7 +88,7 @@ def _run(eng, steps=3, accum=2):
 
 
 @pytest.mark.parametrize("kind", ["single", "ddp", "zero2", "fsdp", "fsdp_keep"])
-@pytest.mark.parametrize("recomp", [False, True])
+@pytest.mark.parametrize("recomp", [False, True, "block"])
 def test_direct_accumulation_matches_autograd_accumulation(kind, recomp, emulate_direct):
     from distributed_pytorch_amd.parallel.ddp import DDPEngine
     from distributed_pytorch_amd.parallel.engine import Engine
@@ -92,7 +97,8 @@ def test_direct_accumulation_matches_autograd_accumulation(kind, recomp, emulate
 
     def make(direct):
         torch.manual_seed(0)
-        m = LLM(LLMconfig(**CFG, act_recomp=recomp).finalize())
+        m = LLM(LLMconfig(**CFG, act_recomp=bool(recomp),
+                          act_recomp_scope="block" if recomp == "block" else "attn").finalize())
         kw = dict(dtype="fp32", eps=1e-5, bucket_mb=0.02)
         eng = {"single": lambda: Engine(m, **kw), "ddp": lambda: DDPEngine(m, **kw),
                "zero2": lambda: ZeroEngine(m, stage=2, **kw), "fsdp": lambda: FSDPEngine(m, **kw),
@@ -107,3 +113,22 @@ def test_direct_accumulation_matches_autograd_accumulation(kind, recomp, emulate
         if want[k].is_complex():
             continue
         assert torch.allclose(got[k], want[k], rtol=1e-4, atol=1e-5), f"{kind}: {k}"
+
+
+@pytest.mark.parametrize("kind", ["single", "fsdp"])
+def test_block_recomputation_matches_plain_backward(kind):
+    """Whole-block recomputation changes memory, not the trajectory."""
+    from distributed_pytorch_amd.parallel.engine import Engine
+    from distributed_pytorch_amd.parallel.fsdp import FSDPEngine
+
+    def make(recomp):
+        torch.manual_seed(0)
+        m = LLM(LLMconfig(**CFG, act_recomp=recomp, act_recomp_scope="block").finalize())
+        kw = dict(dtype="fp32", eps=1e-5)
+        return Engine(m, **kw) if kind == "single" else FSDPEngine(m, **kw)
+
+    want = _run(make(False))
+    got = _run(make(True))
+    for k in want:
+        if not want[k].is_complex():
+            assert torch.allclose(got[k], want[k], rtol=1e-5, atol=1e-6), f"{kind}: {k}"

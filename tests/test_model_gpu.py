@@ -19,6 +19,8 @@ VARIANTS = {
     "mla_naive_flash": dict(attn="mla", pos_emb="learn", q_latent_dim=64, kv_latent_dim=64),
     "moe": dict(attn="mha", pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2),
     "recompute": dict(attn="mha", pos_emb="learn", non_linearity="gelu", act_recomp=True),
+    "recompute_block": dict(attn="mha", pos_emb="learn", non_linearity="gelu", act_recomp=True,
+                            act_recomp_scope="block"),
 }
 
 
