@@ -58,8 +58,8 @@ class ZeroEngine(DDPEngine):
         self._have_norm = True
 
     def _apply_updates(self, lr: float):
-        # update in reverse bucket order and start each bucket's all-gather right away, so the
-        # gathers of late buckets overlap the AdamW of earlier ones
+        # start each bucket's all-gather right after its update, so the gathers overlap the AdamW of
+        # the following buckets
         for gi in range(len(self.groups)):
             g, o = self.groups[gi], self.optims[gi]
             o.step(g.grad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
