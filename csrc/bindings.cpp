@@ -626,9 +626,23 @@ std::tuple<Tensor, Tensor> wgrad2_slabs_bias(const Tensor& dy, const Tensor& x) 
   return {slabs, colsum(dy)};
 }
 
+// dst_g (+)= ws[g] for every g: ws fp32 [G, ...], dst_ptrs int64 [G] device addresses of equally sized,
+// 16-byte aligned destinations (checked by the caller, which owns the tensors behind the addresses).
+void ws_to_many(const Tensor& ws, const Tensor& dst_ptrs, bool accumulate, bool out_bf16) {
+  TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.dim() >= 2, "ws_to_many: fp32 [G, ...]");
+  TORCH_CHECK(dst_ptrs.is_cuda() && dst_ptrs.scalar_type() == at::kLong && dst_ptrs.is_contiguous() &&
+                  dst_ptrs.numel() == ws.size(0),
+              "ws_to_many: one destination address per slab");
+  const int64_t n = ws.numel() / ws.size(0);
+  TORCH_CHECK(n % 8 == 0, "ws_to_many: slab size must be a multiple of 8");
+  dpa::wgrad_finish_many(ws.data_ptr<float>(), (const long long*)dst_ptrs.data_ptr<int64_t>(), (int)ws.size(0), n,
+                         accumulate, out_bf16, cur_stream());
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dpa, m) {
+  m.def("ws_to_many(Tensor ws, Tensor dst_ptrs, bool accumulate, bool out_bf16) -> ()");
   m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
   m.def("moe_topk_gate(Tensor logits, Tensor? bias, int k) -> (Tensor, Tensor)");
   m.def("moe_plan(Tensor idx, int n_experts, int rows) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
@@ -672,6 +686,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
+  m.impl("ws_to_many", ws_to_many);
   m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);
   m.impl("moe_topk_gate", moe_topk_gate);
   m.impl("moe_plan", moe_plan);

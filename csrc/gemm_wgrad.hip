@@ -391,6 +391,41 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   }
 }
 
+// The same fold for a batch of equally sized destinations given by address (the experts of a MoE
+// layer live at different places of the flat gradient buffer): out_g (+)= ws[g], one launch.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_finish_many_kernel(const float* __restrict__ ws,
+                                                                const long long* __restrict__ dst_ptrs,
+                                                                long long nvec, int accumulate) {
+  const float* src = ws + (long long)blockIdx.y * nvec * 8;
+  T* out = reinterpret_cast<T*>(dst_ptrs[blockIdx.y]);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    float a[8];
+    load8(src + i * 8, a);
+    if (accumulate) {
+      float o[8];
+      load8(out + i * 8, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += o[j];
+    }
+    store8(out + i * 8, a);
+  }
+}
+
+void wgrad_finish_many(const float* ws, const long long* dst_ptrs, int count, long long n, bool accumulate,
+                       bool out_bf16, hipStream_t st) {
+  const long long nvec = n >> 3;
+  if (nvec == 0 || count == 0) return;
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  const dim3 grid((unsigned)blocks, (unsigned)count), block(256);
+  if (out_bf16)
+    hipLaunchKernelGGL((wgrad_finish_many_kernel<bf16_t>), grid, block, 0, st, ws, dst_ptrs, nvec, accumulate ? 1 : 0);
+  else
+    hipLaunchKernelGGL((wgrad_finish_many_kernel<float>), grid, block, 0, st, ws, dst_ptrs, nvec, accumulate ? 1 : 0);
+}
+
 int wgrad_splits(int M, int N, int K) {
   const int tiles = (N / kWgTile) * (K / kWgTile);
   int s = (512 + tiles - 1) / tiles;          // aim at >= 2 workgroups per CU

@@ -85,6 +85,9 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
                  int splits, hipStream_t st, float* bias_slabs = nullptr);
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
                   hipStream_t st);
+// out_g (+)= ws[g] for `count` destinations of n elements each, given by device addresses.
+void wgrad_finish_many(const float* ws, const long long* dst_ptrs, int count, long long n, bool accumulate,
+                       bool out_bf16, hipStream_t st);
 
 // ---- Grouped GEMM (MoE experts) ----------------------------------------------------------------
 // c[rows, N] = a[rows, K] * W_g, one weight matrix per 128-row block (block_group[rb]; values outside

@@ -122,18 +122,30 @@ def _act_bwd(da, h, act):
     return ops().swiglu_bwd(da, h) if act == "swiglu" else ops().gelu_bwd(da, h)
 
 
+def _direct_grad(p):
+    """The flat-buffer gradient view of ``p`` if its engine asked for direct accumulation, else None."""
+    g = p.grad if getattr(p, "_dpa_direct", False) else None
+    if g is not None and g.is_contiguous() and g.dtype in (torch.bfloat16, torch.float32) \
+            and g.data_ptr() % 16 == 0 and g.numel() % 8 == 0:
+        return g
+    return None
+
+
 def _emit_wgrads(ws32, params, needs):
     """fp32 [E, N, K] gradients -> per-parameter results: accumulated straight into the engine's
-    flat gradient buffer when the parameter asks for it (``_dpa_direct``), else bf16 tensors."""
+    flat gradient buffer when the parameters ask for it (``_dpa_direct``; one launch for all
+    experts), else bf16 tensors returned to autograd."""
+    targets = [_direct_grad(p) if needs[i] else None for i, p in enumerate(params)]
+    if all(t is not None for t in targets) and len({t.dtype for t in targets}) == 1:
+        ops().ws_to_many(ws32, _ptr_table(targets), True, targets[0].dtype == torch.bfloat16)
+        return [None] * len(params)
     out = [None] * len(params)
     lazy = None
     for i, p in enumerate(params):
         if not needs[i]:
             continue
-        g = p.grad if getattr(p, "_dpa_direct", False) else None
-        if g is not None and g.is_contiguous() and g.dtype in (torch.bfloat16, torch.float32) \
-                and g.data_ptr() % 16 == 0 and g.numel() % 8 == 0:
-            ops().ws_to(ws32[i], g, True)
+        if targets[i] is not None:
+            ops().ws_to(ws32[i], targets[i], True)
         else:
             if lazy is None:
                 lazy = torch.empty(ws32.shape, dtype=torch.bfloat16, device=ws32.device)
