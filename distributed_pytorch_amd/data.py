@@ -55,7 +55,7 @@ class DataLoader:
         return {"gen": self.gen.get_state()}
 
     def load_state_dict(self, sd):
-        self.gen.set_state(sd["gen"])
+        self.gen.set_state(sd["gen"].cpu())   # a resume file may have been mapped to the GPU
 
     def _starts(self) -> np.ndarray:
         s = torch.randint(0, self.N - self.T - 1, (self.B * self.world,), generator=self.gen)

@@ -136,3 +136,20 @@ def test_graphed_step_matches_eager_steps():
     w1 = e1.state_dict()["lm_head.weight"]
     w2 = e2.state_dict()["lm_head.weight"]
     assert ((w1 - w2).norm() / w1.norm()).item() < 2e-2
+
+
+def test_trainer_resume_on_gpu(tmp_path):
+    """Save a resume file mid-run on the GPU, continue from it in a new trainer call (loader RNG state
+    comes back from a file mapped to the GPU) and land on the same loss as the uninterrupted run."""
+    from distributed_pytorch_amd.config import Trainconfig
+    from distributed_pytorch_amd.trainer import train
+    mc = LLMconfig(**BASE, **VARIANTS["gpt2"]).finalize()
+
+    def tc(max_iters, resume=""):
+        return Trainconfig(dataset="synthetic", synthetic_tokens=200_000, data_dir=str(tmp_path / "data"), batch_size=4,
+                           total_batch_size=4 * 256, max_iters=max_iters, learning_rate=1e-3, warmup_steps=2,
+                           dtype="bf16", save_interval=4, file_name=str(tmp_path / "run"), resume=resume, log_interval=100)
+    full = train(tc(8), mc, "single")
+    train(tc(4), mc, "single")                       # writes run_resume.rank0 at iteration 4
+    cont = train(tc(8, resume=str(tmp_path / "run_resume")), mc, "single")
+    assert abs(cont["final_loss"] - full["final_loss"]) < 2e-2 * abs(full["final_loss"])
