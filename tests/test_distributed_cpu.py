@@ -91,6 +91,16 @@ def test_matches_single_process(mode, cfg_name):
         assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
 
 
+@pytest.mark.parametrize("mode", ["ddp", "zero2", "fsdp"])
+def test_four_ranks_match_single_process(mode):
+    """World size 4 (shards of a quarter, uneven bucket tails, two prefetches in flight): same
+    trajectory as one process on the same global batches."""
+    want = _single_reference("gpt", n_steps=2, global_b=8, accum=1)
+    got = run_distributed(_worker, 4, mode, "gpt", 2, 8, 1)[0]
+    for k in want:
+        assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
+
+
 def _collective_bytes_worker(rank, world):
     from distributed_pytorch_amd.parallel import comm
     from distributed_pytorch_amd.parallel.zero import ZeroEngine
