@@ -101,6 +101,15 @@ def test_four_ranks_match_single_process(mode):
         assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
 
 
+@pytest.mark.parametrize("mode", ["ddp", "fsdp"])
+def test_eight_ranks_match_single_process(mode):
+    """The world size of one MI355X node."""
+    want = _single_reference("gpt", n_steps=2, global_b=8, accum=1)
+    got = run_distributed(_worker, 8, mode, "gpt", 2, 8, 1)[0]
+    for k in want:
+        assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}/8: {k} differs"
+
+
 def _collective_bytes_worker(rank, world):
     from distributed_pytorch_amd.parallel import comm
     from distributed_pytorch_amd.parallel.zero import ZeroEngine
