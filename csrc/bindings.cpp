@@ -84,7 +84,7 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor&
     db.zero_();
     return {dx, dw, db};
   }
-  const int nparts = dpa::layernorm_bwd_parts((int)rows);
+  const int nparts = dpa::layernorm_bwd_parts((int)rows, (int)C);
   Tensor scratch = at::empty({2 * (int64_t)nparts * C}, x.options().dtype(at::kFloat));
   dpa::layernorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
                      opt_ptr(dres), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), scratch.data_ptr<float>(), nparts,

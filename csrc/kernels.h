@@ -8,7 +8,7 @@ namespace dpa {
 
 // ---- LayerNorm -------------------------------------------------------------------------
 int layernorm_max_cols();
-int layernorm_bwd_parts(int rows);
+int layernorm_bwd_parts(int rows, int C);
 void layernorm_fwd(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out,
                    float* mean, float* rstd, int rows, int C, float eps, bool is_bf16, hipStream_t st);
 void layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,

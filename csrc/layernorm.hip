@@ -323,9 +323,20 @@ static void ln_bwd_launch(const T* dy, const T* x, const T* w, const float* mean
 
 int layernorm_max_cols() { return 16 * 64 * 8; }  // 8192; LDS in the backward: 8*C*4 B <= 160 KiB -> C <= 5120
 
-int layernorm_bwd_parts(int rows) {
-  int n = (rows + 7) / 8;
-  return n < 1 ? 1 : (n > 768 ? 768 : n);  // 3 workgroups (12 waves) per CU keep HBM busy
+int layernorm_bwd_parts(int rows, int C) {
+  // One round of resident workgroups: LDS (2 * rows-per-block * C floats) and registers allow three
+  // per CU for narrow rows, two from C = 2048 on; a partial second round would run at half occupancy.
+  int lpr, nch;
+  pick_shape(C, lpr, nch);
+  const int rpb = 4 * (64 / lpr);
+  const long long lds = 2LL * rpb * C * 4;
+  int per_cu = (int)(160 * 1024 / (lds > 0 ? lds : 1));
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu < 1) per_cu = 1;
+  if (nch * 2 > 6 && per_cu > 2) per_cu = 2;   // register budget of the wide-row instantiations
+  const int cap = 256 * per_cu;
+  const int n = (rows + rpb - 1) / rpb;
+  return n < 1 ? 1 : (n > cap ? cap : n);
 }
 
 void layernorm_fwd(const void* x, const void* res, const void* w, const void* b, void* y, void* sum_out,
