@@ -11,6 +11,8 @@ Reference behaviour: ``nn.Linear`` (reference: single-gpu/model.py:112-114,373-3
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -36,7 +38,7 @@ def wgrad2_supported(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
 # kernels (measured on MI355X, benchmarks/wgrad_shapes_bench.py: own kernels win up to 4.2 M output
 # elements, the library from 12.6 M; a 256x256 tiling of a large output no longer divides evenly
 # over 256 CUs and the split-M advantage is gone).
-LIBRARY_WGRAD_MIN_OUT = 8 * 1024 * 1024
+LIBRARY_WGRAD_MIN_OUT = int(os.environ.get("DPA_LIBRARY_WGRAD_MIN_OUT", 8 * 1024 * 1024))
 
 
 def _library_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
