@@ -589,20 +589,22 @@ std::tuple<Tensor, Tensor> moe_topk_gate(const Tensor& logits, const std::option
 // (row_of_pair [npairs] int64, block_group [rows / 128] int32, seg_start, seg_rows, counts [E] int64)
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> moe_plan(const Tensor& idx, int64_t n_experts, int64_t rows) {
   TORCH_CHECK(idx.is_cuda() && idx.scalar_type() == at::kLong && idx.is_contiguous(), "moe_plan: int64 expert ids");
-  TORCH_CHECK(n_experts >= 1 && n_experts <= 64 && rows % 128 == 0, "moe_plan: E <= 64, rows % 128 == 0");
   const int64_t npairs = idx.numel();
-  TORCH_CHECK(rows >= npairs + n_experts * 127, "moe_plan: row bound too small for the padded layout");
+  const bool dense = rows == npairs;     // unpadded layout (expert-sorted send order)
+  TORCH_CHECK(n_experts >= 1 && n_experts <= 64, "moe_plan: E <= 64");
+  TORCH_CHECK(dense || (rows % 128 == 0 && rows >= npairs + n_experts * 127),
+              "moe_plan: rows is either the pair count (dense) or a multiple of 128 >= pairs + 127 * E");
   auto opt = idx.options();
   Tensor row_of_pair = at::empty({npairs}, opt);
-  Tensor block_group = at::empty({rows / 128}, opt.dtype(at::kInt));
+  Tensor block_group = at::empty({dense ? 0 : rows / 128}, opt.dtype(at::kInt));
   Tensor seg_start = at::empty({n_experts}, opt), seg_rows = at::empty({n_experts}, opt);
   Tensor counts = at::empty({n_experts}, opt);
   const int nb = dpa::moe_plan_blocks(npairs);
   Tensor hist = at::empty({std::max<int64_t>(nb, 1) * n_experts}, opt.dtype(at::kInt));
-  dpa::moe_plan((const long long*)idx.data_ptr<int64_t>(), npairs, (int)n_experts, (int)(rows / 128),
-                hist.data_ptr<int>(), (long long*)row_of_pair.data_ptr<int64_t>(), block_group.data_ptr<int>(),
-                (long long*)seg_start.data_ptr<int64_t>(), (long long*)seg_rows.data_ptr<int64_t>(),
-                (long long*)counts.data_ptr<int64_t>(), cur_stream());
+  dpa::moe_plan((const long long*)idx.data_ptr<int64_t>(), npairs, (int)n_experts, dense ? 0 : (int)(rows / 128),
+                dense ? 1 : 128, hist.data_ptr<int>(), (long long*)row_of_pair.data_ptr<int64_t>(),
+                dense ? nullptr : block_group.data_ptr<int>(), (long long*)seg_start.data_ptr<int64_t>(),
+                (long long*)seg_rows.data_ptr<int64_t>(), (long long*)counts.data_ptr<int64_t>(), cur_stream());
   return {row_of_pair, block_group, seg_start, seg_rows, counts};
 }
 

@@ -113,10 +113,11 @@ void moe_combine_bwd(const void* dout, const void* y, const long long* row_of_pa
 // selected raw logits.
 void moe_topk_gate(const float* logits, const float* bias, long long* idx, float* gates, long long ntok, int E, int k,
                    hipStream_t st);
-// Expert-sorted padded layout of the [npairs] expert ids (see csrc/moe_route.hip). hist is scratch of
-// moe_plan_blocks(npairs) * E ints; nrb = padded rows / 128.
+// Expert-sorted layout of the [npairs] expert ids (see csrc/moe_route.hip). pad = 128: every expert's
+// segment is padded to whole 128-row blocks and block_group[nrb] is filled; pad = 1: dense (the send
+// order of an all-to-all), block_group untouched. hist is scratch of moe_plan_blocks(npairs) * E ints.
 int moe_plan_blocks(long long npairs);
-void moe_plan(const long long* idx, long long npairs, int E, int nrb, int* hist, long long* row_of_pair,
+void moe_plan(const long long* idx, long long npairs, int E, int nrb, int pad, int* hist, long long* row_of_pair,
               int* block_group, long long* seg_start, long long* seg_rows, long long* counts, hipStream_t st);
 
 // ---- Column sums (bias gradients) ----------------------------------------------------------

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void moe_plan_hist_kernel(const long long* __re
 
 // One workgroup. Thread e < E scans its expert's column of the histogram; the table is staged in
 // LDS with coalesced accesses when it fits (nblocks * E <= 8192), else walked in global memory.
-__global__ __launch_bounds__(64) void moe_plan_scan_kernel(int* __restrict__ hist, int nblocks, int E, int nrb,
+__global__ __launch_bounds__(64) void moe_plan_scan_kernel(int* __restrict__ hist, int nblocks, int E, int nrb, int pad,
                                                            long long* __restrict__ seg_start,
                                                            long long* __restrict__ seg_rows,
                                                            long long* __restrict__ counts,
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void moe_plan_scan_kernel(int* __restrict__ his
       run += v;
     }
   }
-  const int padded = lane < E ? (run + 127) / 128 * 128 : 0;
+  const int padded = lane < E ? (run + pad - 1) / pad * pad : 0;   // pad = 128 (GEMM blocks) or 1 (dense)
   int incl = padded;                          // inclusive scan over the experts (lanes)
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -124,14 +124,16 @@ __global__ __launch_bounds__(64) void moe_plan_scan_kernel(int* __restrict__ his
     seg_rows[lane] = padded;
     counts[lane] = run;
     for (int b = 0; b < nblocks; ++b) tab[b * E + lane] += start;   // absolute row base
-    for (int rb = start / 128; rb < (start + padded) / 128; ++rb) block_group[rb] = lane;
+    if (pad == 128)
+      for (int rb = start / 128; rb < (start + padded) / 128; ++rb) block_group[rb] = lane;
   }
   if (in_lds) {
     __syncthreads();
     for (int i = lane; i < total_cells; i += 64) hist[i] = sh[i];
   }
   const int total = __shfl(incl, 63, 64);
-  for (int rb = total / 128 + lane; rb < nrb; rb += 64) block_group[rb] = E;   // blocks past the last segment
+  if (pad == 128)
+    for (int rb = total / 128 + lane; rb < nrb; rb += 64) block_group[rb] = E;   // blocks past the last segment
 }
 
 __global__ __launch_bounds__(64) void moe_plan_place_kernel(const long long* __restrict__ idx, long long npairs, int E,
@@ -168,11 +170,11 @@ void moe_topk_gate(const float* logits, const float* bias, long long* idx, float
 
 int moe_plan_blocks(long long npairs) { return (int)((npairs + kPlanChunk - 1) / kPlanChunk); }
 
-void moe_plan(const long long* idx, long long npairs, int E, int nrb, int* hist, long long* row_of_pair,
+void moe_plan(const long long* idx, long long npairs, int E, int nrb, int pad, int* hist, long long* row_of_pair,
               int* block_group, long long* seg_start, long long* seg_rows, long long* counts, hipStream_t st) {
   const int nb = moe_plan_blocks(npairs);
   if (nb > 0) hipLaunchKernelGGL(moe_plan_hist_kernel, dim3(nb), dim3(64), 0, st, idx, npairs, E, hist);
-  hipLaunchKernelGGL(moe_plan_scan_kernel, dim3(1), dim3(64), 0, st, hist, nb, E, nrb, seg_start, seg_rows, counts,
+  hipLaunchKernelGGL(moe_plan_scan_kernel, dim3(1), dim3(64), 0, st, hist, nb, E, nrb, pad, seg_start, seg_rows, counts,
                      block_group);
   if (nb > 0)
     hipLaunchKernelGGL(moe_plan_place_kernel, dim3(nb), dim3(64), 0, st, idx, npairs, E, hist, row_of_pair);

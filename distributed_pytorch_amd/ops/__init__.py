@@ -5,7 +5,8 @@ from .attention import (causal_attention, causal_attention_eager, causal_self_at
 from .embedding import embedding
 from .linear import linear, weight_grad, wgrad_supported
 from .loss import IGNORE_INDEX, cross_entropy, linear_cross_entropy, vocab_parallel_cross_entropy
-from .moe import expert_counts, grouped_experts, grouped_experts_eager, grouped_supported, topk_gate
+from .moe import (expert_counts, gather_combine, grouped_experts, grouped_experts_eager, grouped_supported,
+                  plan_dense, scatter_rows, topk_gate)
 from .moe import plan as moe_plan
 from .norm import add_layer_norm, layer_norm
 from .optim import adamw_step, sumsq
@@ -16,5 +17,5 @@ __all__ = [
     "split_qkv", "embedding", "cross_entropy", "linear_cross_entropy", "vocab_parallel_cross_entropy",
     "IGNORE_INDEX", "layer_norm", "add_layer_norm", "adamw_step", "sumsq", "apply_rope", "rope_inplace_",
     "rope_tables", "linear", "weight_grad", "wgrad_supported", "grouped_experts", "grouped_experts_eager",
-    "grouped_supported", "expert_counts", "topk_gate", "moe_plan",
+    "grouped_supported", "expert_counts", "topk_gate", "moe_plan", "plan_dense", "scatter_rows", "gather_combine",
 ]

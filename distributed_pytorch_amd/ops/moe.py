@@ -68,6 +68,70 @@ def plan(topk_indices: torch.Tensor, n_experts: int):
     return row_of_pair, block_group, seg_start.contiguous(), seg_rows.contiguous(), rows, counts
 
 
+def plan_dense(topk_indices: torch.Tensor, n_experts: int):
+    """Unpadded expert-sorted order of the (token, slot) pairs: -> (row_of_pair [N*k] int64, counts [E]
+    int64). Row ``row_of_pair[t*k + s]`` of a buffer laid out this way holds pair ``(t, s)``; pairs of one
+    expert are contiguous and keep their order, which is the send order of an expert-parallel
+    all-to-all (experts are owned by ranks in contiguous blocks)."""
+    flat_e = topk_indices.reshape(-1)
+    npairs = flat_e.numel()
+    if use_hip(flat_e) and n_experts <= 64 and flat_e.dtype == torch.int64 and npairs > 0:
+        row_of_pair, _, _, _, counts = ops().moe_plan(flat_e.contiguous(), n_experts, npairs)
+        return row_of_pair, counts
+    order = torch.argsort(flat_e, stable=True)
+    row_of_pair = torch.empty_like(order)
+    row_of_pair[order] = torch.arange(npairs, device=flat_e.device)
+    return row_of_pair, expert_counts(flat_e, n_experts)
+
+
+class _ScatterRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, row_of_pair, k, rows):
+        ctx.save_for_backward(row_of_pair)
+        ctx.k = k
+        return ops().moe_scatter_rows(x.contiguous(), row_of_pair, k, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (row_of_pair,) = ctx.saved_tensors
+        return ops().moe_gather_combine(g.contiguous(), row_of_pair, None, ctx.k), None, None, None
+
+
+class _GatherCombineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, row_of_pair, gates, k):
+        yc, gc = y.contiguous(), gates.contiguous()
+        ctx.save_for_backward(yc, row_of_pair, gc)
+        return ops().moe_gather_combine(yc, row_of_pair, gc, k)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, row_of_pair, gates = ctx.saved_tensors
+        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        return dy, None, dgate.to(gates.dtype), None
+
+
+def _rows_hip_ok(x, row_of_pair) -> bool:
+    return use_hip(x, row_of_pair) and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] % 8 == 0 \
+        and row_of_pair.numel() > 0
+
+
+def scatter_rows(x: torch.Tensor, row_of_pair: torch.Tensor, k: int, rows: int) -> torch.Tensor:
+    """out[row_of_pair[t*k + s]] = x[t] (other rows zero); differentiable in x."""
+    if _rows_hip_ok(x, row_of_pair):
+        return _ScatterRowsFn.apply(x, row_of_pair, k, rows)
+    out = x.new_zeros(rows, x.shape[1])
+    return out.index_copy(0, row_of_pair, x.repeat_interleave(k, 0))
+
+
+def gather_combine(y: torch.Tensor, row_of_pair: torch.Tensor, gates: torch.Tensor, k: int) -> torch.Tensor:
+    """out[t] = sum_s gates[t, s] * y[row_of_pair[t*k + s]]; differentiable in y and gates."""
+    if _rows_hip_ok(y, row_of_pair) and gates.dtype == torch.bfloat16:
+        return _GatherCombineFn.apply(y, row_of_pair, gates, k)
+    picked = y[row_of_pair].view(-1, k, y.shape[1])
+    return (picked * gates.unsqueeze(-1).to(picked.dtype)).sum(1)
+
+
 class _TopkGateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, bias, k):

@@ -77,16 +77,14 @@ class ExpertParallelDispatcher:
     def __call__(self, moe, x_flat, topk_indices, topk_gates):
         W, per = self.world, moe.n_routed // self.world
         N, k = topk_indices.shape
-        flat_e = topk_indices.reshape(-1)
-        order = torch.argsort(flat_e, stable=True)
-        tok = torch.div(order, k, rounding_mode="floor")
-        counts = ops.expert_counts(flat_e, moe.n_routed)                    # rows per expert (global ids)
+        # expert-sorted (== destination-rank-sorted) send order, computed on the device
+        row_of_pair, counts = ops.plan_dense(topk_indices, moe.n_routed)   # counts: rows per expert (global ids)
         recv_counts = torch.empty_like(counts)
         comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
         recv_mat = recv_counts.view(W, per)
         # the one host read of the layer: rows sent to / received from each rank (the all-to-all splits)
         counts_h, recv_h = torch.stack([counts.view(W, per).sum(1), recv_mat.sum(1)]).tolist()
-        xs = x_flat[tok]
+        xs = ops.scatter_rows(x_flat, row_of_pair, k, N * k)
         recv = all_to_all_rows(xs, counts_h, recv_h, self.group)
         # regroup the received rows (ordered by source rank, then expert) by local expert
         R = recv.shape[0]
@@ -118,8 +116,7 @@ class ExpertParallelDispatcher:
                 y_grouped = y_grouped + 0.0 * sum(p.sum() for m in local for p in m.parameters())
             y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
         y_back = all_to_all_rows(y_recv, recv_h, counts_h, self.group)
-        gs = topk_gates.reshape(-1)[order].unsqueeze(1)
-        return torch.zeros_like(x_flat).index_add_(0, tok, (y_back * gs).to(x_flat.dtype))
+        return ops.gather_combine(y_back, row_of_pair, topk_gates, k).to(x_flat.dtype)
 
 
 def _expert_index(name: str):

@@ -498,3 +498,40 @@ def test_wgrad_with_fused_bias_sums(M, N, K):
     assert db.dtype == torch.float32 and db.shape == (N,)
     assert rel_err(slabs.sum(0), dy.float().t() @ x.float()) < 1e-5
     assert rel_err(db, dy.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("N,E,k,C", [(4096, 8, 2, 768), (77, 4, 1, 128), (1000, 16, 4, 256)])
+def test_dense_plan_scatter_and_combine(N, E, k, C):
+    """Unpadded expert-sorted order (the expert-parallel send order) and the differentiable row
+    scatter / gate-weighted combine built on it, against their PyTorch statements."""
+    import os
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    idx = torch.stack([torch.randperm(E, device=DEV)[:k] for _ in range(N)])
+    rop, counts = ops.plan_dense(idx, E)
+    os.environ["DPA_FORCE_EAGER"] = "1"
+    try:
+        rop_ref, counts_ref = ops.plan_dense(idx, E)
+    finally:
+        del os.environ["DPA_FORCE_EAGER"]
+    assert torch.equal(rop, rop_ref) and torch.equal(counts, counts_ref)
+    x = torch.randn(N, C, device=DEV, dtype=torch.bfloat16)
+    gates = torch.softmax(torch.randn(N, k, device=DEV), 1).to(torch.bfloat16)
+    dout = torch.randn(N, C, device=DEV, dtype=torch.bfloat16)
+
+    def run(eager):
+        if eager:
+            os.environ["DPA_FORCE_EAGER"] = "1"
+        try:
+            xi = x.clone().float().requires_grad_() if eager else x.clone().requires_grad_()
+            gi = gates.clone().float().requires_grad_() if eager else gates.clone().requires_grad_()
+            xs = ops.scatter_rows(xi, rop, k, N * k)
+            out = ops.gather_combine(xs * 2.0, rop, gi, k)
+            out.backward(dout.float() if eager else dout)
+            return out, xi.grad, gi.grad
+        finally:
+            os.environ.pop("DPA_FORCE_EAGER", None)
+
+    got, want = run(False), run(True)
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < 1.5e-2
