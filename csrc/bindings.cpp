@@ -58,9 +58,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_fwd(const Tensor& x, const 
   return {y, sum, mean, rstd};
 }
 
-std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& w,
-                                                 const Tensor& mean, const Tensor& rstd,
-                                                 const std::optional<Tensor>& dres) {
+// dw_acc / db_acc given: the parameter gradients are ADDED into them (the engine's flat gradient views)
+// and the returned dw / db are empty; otherwise fresh dw / db are returned.
+std::tuple<Tensor, Tensor, Tensor> layernorm_bwd_impl(const Tensor& dy, const Tensor& x, const Tensor& w,
+                                                      const Tensor& mean, const Tensor& rstd,
+                                                      const std::optional<Tensor>& dres,
+                                                      const std::optional<Tensor>& dw_acc,
+                                                      const std::optional<Tensor>& db_acc) {
   check_act(dy, "dy");
   check_act(x, "x");
   check_act(w, "weight");
@@ -76,20 +80,40 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor&
     check_act(*dres, "dres");
     TORCH_CHECK(dres->sizes() == x.sizes() && dres->scalar_type() == x.scalar_type(), "dres mismatch");
   }
+  const bool acc = dw_acc.has_value();
+  if (acc) {
+    TORCH_CHECK(db_acc.has_value(), "layernorm backward: dw_acc and db_acc go together");
+    for (const Tensor* t : {&*dw_acc, &*db_acc})
+      TORCH_CHECK(t->is_cuda() && t->is_contiguous() && t->numel() == C && t->scalar_type() == w.scalar_type(),
+                  "layernorm backward: accumulation targets must be contiguous [C] of the weight dtype");
+  }
   Tensor dx = at::empty_like(x);
-  Tensor dw = at::empty_like(w);
-  Tensor db = at::empty_like(w);
+  Tensor dw = acc ? *dw_acc : at::empty_like(w);
+  Tensor db = acc ? *db_acc : at::empty_like(w);
   if (rows == 0) {
-    dw.zero_();
-    db.zero_();
-    return {dx, dw, db};
+    if (!acc) {
+      dw.zero_();
+      db.zero_();
+    }
+    return {dx, acc ? Tensor() : dw, acc ? Tensor() : db};
   }
   const int nparts = dpa::layernorm_bwd_parts((int)rows, (int)C);
   Tensor scratch = at::empty({2 * (int64_t)nparts * C}, x.options().dtype(at::kFloat));
   dpa::layernorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
                      opt_ptr(dres), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), scratch.data_ptr<float>(), nparts,
-                     (int)rows, (int)C, false, is_bf16(x), cur_stream());
-  return {dx, dw, db};
+                     (int)rows, (int)C, acc, is_bf16(x), cur_stream());
+  return {dx, acc ? Tensor() : dw, acc ? Tensor() : db};
+}
+
+std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& w,
+                                                 const Tensor& mean, const Tensor& rstd,
+                                                 const std::optional<Tensor>& dres) {
+  return layernorm_bwd_impl(dy, x, w, mean, rstd, dres, std::nullopt, std::nullopt);
+}
+
+Tensor layernorm_bwd_acc(const Tensor& dy, const Tensor& x, const Tensor& w, const Tensor& mean, const Tensor& rstd,
+                         const std::optional<Tensor>& dres, Tensor dw_acc, Tensor db_acc) {
+  return std::get<0>(layernorm_bwd_impl(dy, x, w, mean, rstd, dres, dw_acc, db_acc));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -662,6 +686,8 @@ TORCH_LIBRARY(dpa, m) {
   m.def("wgrad2_accum(Tensor dy, Tensor x, Tensor(a!) ws) -> ()");
   m.def("layernorm_fwd(Tensor x, Tensor? res, Tensor w, Tensor b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres) -> (Tensor, Tensor, Tensor)");
+  m.def("layernorm_bwd_acc(Tensor dy, Tensor x, Tensor w, Tensor mean, Tensor rstd, Tensor? dres, Tensor(a!) dw_acc, "
+        "Tensor(b!) db_acc) -> Tensor");
   m.def("adamw_step(Tensor(a!) master, Tensor(b!) m, Tensor(c!) v, Tensor grad, Tensor? param_out, int[] seg_ends, "
         "float[] seg_wds, float lr, float beta1, float beta2, float eps, int step, Tensor? norm2, float max_norm, "
         "float grad_mul, Tensor? dyn) -> ()");
@@ -705,6 +731,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("wgrad2_accum", wgrad2_accum);
   m.impl("layernorm_fwd", layernorm_fwd);
   m.impl("layernorm_bwd", layernorm_bwd);
+  m.impl("layernorm_bwd_acc", layernorm_bwd_acc);
   m.impl("adamw_step", adamw_step);
   m.impl("sumsq", sumsq);
   m.impl("xent_fused", xent_fused);

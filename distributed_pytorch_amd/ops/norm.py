@@ -22,9 +22,22 @@ def _hip_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
             and x.dtype in (torch.bfloat16, torch.float32))
 
 
+def _direct_targets(w, b):
+    """(w.grad, b.grad) when the owning engine asked for direct accumulation (``_dpa_direct``) and both
+    are flat-buffer views the kernel can add into, else None."""
+    if not (getattr(w, "_dpa_direct", False) and getattr(b, "_dpa_direct", False)):
+        return None
+    gw, gb = w.grad, b.grad
+    for g, p in ((gw, w), (gb, b)):
+        if g is None or g.dtype != p.dtype or not g.is_contiguous() or g.shape != p.shape:
+            return None
+    return gw, gb
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, w, b, eps):
+        ctx.params = (w, b)
         xc = x.contiguous()
         rc = res.contiguous() if res is not None else None
         y, s, mean, rstd = ops().layernorm_fwd(xc, rc, w, b, eps)
@@ -43,11 +56,21 @@ class _LayerNormFn(torch.autograd.Function):
             if dy is None:
                 return ds, ds, None, None, None
             dres = ds.contiguous() if ds is not None else None
-            dx, dw, db = ops().layernorm_bwd(dy.contiguous(), ln_in, w, mean, rstd, dres)
+            dx, dw, db = _ln_backward(ctx, dy.contiguous(), ln_in, w, mean, rstd, dres)
             return dx, dx, dw, db, None
         (dy,) = grads
-        dx, dw, db = ops().layernorm_bwd(dy.contiguous(), ln_in, w, mean, rstd, None)
+        dx, dw, db = _ln_backward(ctx, dy.contiguous(), ln_in, w, mean, rstd, None)
         return dx, None, dw, db, None
+
+
+def _ln_backward(ctx, dy, ln_in, w, mean, rstd, dres):
+    """dx plus the parameter gradients, which are added straight into the engine's flat gradient
+    buffer when the parameters ask for it (None is then returned for them; their post-accumulate
+    hooks fire all the same)."""
+    tgt = _direct_targets(*ctx.params) if ctx.needs_input_grad[2] and ctx.needs_input_grad[3] else None
+    if tgt is not None:
+        return ops().layernorm_bwd_acc(dy, ln_in, w, mean, rstd, dres, tgt[0], tgt[1]), None, None
+    return ops().layernorm_bwd(dy, ln_in, w, mean, rstd, dres)
 
 
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

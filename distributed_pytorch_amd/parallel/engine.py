@@ -120,9 +120,12 @@ class Engine(nn.Module):
         import os
         if self.device.type != "cuda" or os.environ.get("DPA_DIRECT_GRAD", "1") != "1":
             return
+        ln_params = set()
+        if os.environ.get("DPA_DIRECT_LN", "1") == "1":
+            ln_params = {id(p) for m in self.module.modules() if isinstance(m, nn.LayerNorm) for p in m.parameters()}
         for g in self.groups:
             for s in g.slots:
-                if s.param.dim() == 2:
+                if s.param.dim() == 2 or id(s.param) in ln_params:   # weight matrices; LayerNorm gamma / beta
                     s.param._dpa_direct = True
 
     def _opt_range(self, g: FlatGroup):
