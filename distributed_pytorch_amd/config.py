@@ -109,7 +109,7 @@ class Trainconfig:
     profile: bool = False
     log_interval: int = 1
     sync_loss_every: int = 1          # host reads the loss every N steps (1 = reference behaviour)
-    hip_graph: bool = False           # capture the whole optimizer step in one hipGraph (single GPU)
+    hip_graph: str = "auto"           # whole optimizer step replayed from one hipGraph: auto | on | off
 
     def to_dict(self) -> dict:
         return asdict(self)
@@ -228,7 +228,8 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--profile", action="store_true")
     p.add_argument("--log_interval", type=int, default=tc.log_interval)
     p.add_argument("--sync_loss_every", type=int, default=tc.sync_loss_every)
-    p.add_argument("--hip_graph", action="store_true")
+    p.add_argument("--hip_graph", type=str, nargs="?", const="on", default=tc.hip_graph, choices=["auto", "on", "off"],
+                   help="replay the whole optimizer step from one hipGraph (single GPU); auto = launch-bound steps only")
     return p
 
 

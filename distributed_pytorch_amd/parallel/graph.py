@@ -37,6 +37,7 @@ class GraphedTrainStep:
         self.grad_clip = float(grad_clip)
         self.warmup = int(warmup)
         self.calls = 0
+        self.failed = False        # capture raised once: stay eager
         self.graph = None
         self.x = self.y = None
         self.loss = None
@@ -71,7 +72,7 @@ class GraphedTrainStep:
         eng = self.engine
         eng._dyn = self._dyn
         try:
-            if self.graph is None and self.calls < self.warmup:
+            if self.failed or (self.graph is None and self.calls < self.warmup):
                 self._set_scalars(lr)
                 loss = self._body([b[0] for b in batches], [b[1] for b in batches])
                 self.calls += 1
@@ -81,9 +82,21 @@ class GraphedTrainStep:
                 self.y = torch.stack([b[1] for b in batches]).clone()
                 count = eng.step_count
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self.loss = self._body(list(self.x.unbind(0)), list(self.y.unbind(0)))
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(graph):
+                        self.loss = self._body(list(self.x.unbind(0)), list(self.y.unbind(0)))
+                except Exception as exc:      # something in this configuration cannot be captured
+                    eng.step_count = count
+                    self.failed = True
+                    self.x = self.y = self.loss = None
+                    torch.cuda.synchronize()
+                    print(f"[hip_graph] capture failed ({type(exc).__name__}: {exc}); continuing eagerly", flush=True)
+                    self._set_scalars(lr)
+                    loss = self._body([b[0] for b in batches], [b[1] for b in batches])
+                    self.calls += 1
+                    return loss * self.accum
+                self.graph = graph
                 eng.step_count = count      # capture records work, it does not run it
             else:
                 for i, (bx, by) in enumerate(batches):

@@ -133,8 +133,14 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         start_iter = load_resume(tc.resume, engine, (train_loader, val_loader), info.rank) + 1
         say(f"resumed from {tc.resume} at iteration {start_iter}")
 
+    # Launch-bound steps (few tokens per step) are replayed from one hipGraph, the role torch.compile
+    # plays in the reference trainer (reference: single-gpu/train.py:262-266). "auto" turns it on for
+    # one GPU and at most 32K tokens per step; a failed capture falls back to eager.
     graphed = None
-    if tc.hip_graph and device.type == "cuda" and not engine._dist:
+    mode_g = str(tc.hip_graph).lower()
+    want_graph = mode_g in ("on", "true", "1") or (
+        mode_g == "auto" and tc.total_batch_size <= 32768 and not tc.profile)
+    if want_graph and device.type == "cuda" and not engine._dist and type(engine).name == "single":
         from .parallel.graph import GraphedTrainStep
         graphed = GraphedTrainStep(engine, grad_accum_steps, tc.grad_clip)
         say("Using hipGraph capture of the optimizer step")
