@@ -25,37 +25,6 @@
 
 namespace dpa {
 
-typedef __attribute__((address_space(1))) const void* gg_gptr_t;
-typedef __attribute__((address_space(3))) void* gg_lptr_t;
-
-// DMA a [128 rows][64 cols] bf16 tile (K-contiguous operand; 128-byte rows, 16 pieces of 8 rows).
-__device__ __forceinline__ void dma_rows128x64(const bf16_t* g, long long ld, int row_limit, char* lds, int wave,
-                                               int lane) {
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) {
-    const int piece = wave * 4 + pc;
-    int row = piece * 8 + (lane >> 3);
-    const int chunk = swz<64>(row, lane & 7);
-    if (row >= row_limit) row = 0;   // rows past the matrix edge: any valid address, results never stored
-    __builtin_amdgcn_global_load_lds((gg_gptr_t)(g + (long long)row * ld + chunk * 8), (gg_lptr_t)(lds + piece * 1024),
-                                     16, 0, 0);
-  }
-}
-
-// DMA a [64 rows][128 cols] bf16 tile (contraction-strided operand; 256-byte rows, 16 pieces of 4 rows).
-__device__ __forceinline__ void dma_rows64x128(const bf16_t* g, long long ld, int col_limit, char* lds, int wave,
-                                               int lane) {
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) {
-    const int piece = wave * 4 + pc;
-    const int row = piece * 4 + (lane >> 4);
-    int chunk = swz<128>(row, lane & 15);
-    if (chunk * 8 >= col_limit) chunk = 0;
-    __builtin_amdgcn_global_load_lds((gg_gptr_t)(g + (long long)row * ld + chunk * 8), (gg_lptr_t)(lds + piece * 1024),
-                                     16, 0, 0);
-  }
-}
-
 // Operand fragment by transposed read in NATURAL k order (element j of lane half hh is
 // contraction index 16*s + 8*hh + j), matching row_frag on the other operand.
 __device__ __forceinline__ bfrag tr_frag_nat128(const char* tile, int s, int dt, int lane) {

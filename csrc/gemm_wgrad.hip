@@ -140,51 +140,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ d
 // ------------------------------------------------------------------------------------------
 constexpr int kW2N = 128, kW2K = 256;
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// DMA a [64 tokens][128 cols] bf16 sub-tile (16 KiB = 16 pieces of 1 KiB) with 4 waves.
-__device__ __forceinline__ void dma_subtile(const bf16_t* g, long long ld, int col_limit, char* lds, int wave,
-                                            int lane) {
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) {
-    const int piece = wave * 4 + pc;
-    const int row = piece * 4 + (lane >> 4);
-    int chunk = swz<128>(row, lane & 15);   // slot -> logical chunk (the swizzle is an involution)
-    if (chunk * 8 >= col_limit) chunk = 0;  // columns past the matrix edge: any valid address, never stored
-    __builtin_amdgcn_global_load_lds((gptr_t)(g + (long long)row * ld + chunk * 8), (lptr_t)(lds + piece * 1024), 16,
-                                     0, 0);
-  }
-}
-
-// The same sub-tile DMA issued from inline assembly: hipcc treats an LDS-DMA builtin as a write to
-// LDS that any later ds_read may alias and drains it (vmcnt(0)) before the next LDS read, which
-// serialises a multi-stage ring. Issued from asm the transfer is invisible to the compiler's wait
-// insertion and is retired by hand with a counted s_waitcnt before the barrier that publishes
-// the stage. M0 (LDS base of the piece) is written and restored inside the same statement.
-__device__ __forceinline__ void dma_subtile_asm(const bf16_t* g, long long ld, int col_limit, unsigned lds_addr,
-                                                int wave, int lane) {
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) {
-    const int piece = wave * 4 + pc;
-    const int row = piece * 4 + (lane >> 4);
-    int chunk = swz<128>(row, lane & 15);
-    if (chunk * 8 >= col_limit) chunk = 0;
-    const bf16_t* src = g + (long long)row * ld + chunk * 8;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + piece * 1024);
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src), "s"(dst)
-        : "memory");
-  }
-}
-
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                      float* __restrict__ slabs, int M, int N, int K, long long ldy,
@@ -214,9 +169,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
   auto issue = [&](int t, int stage) {
     const long long m = m_begin + (long long)t * 64;
     char* base = smem + stage * STAGE;
-    dma_subtile(dy + m * ldy + n0, ldy, N - n0, base, wave, lane);
-    dma_subtile(x + m * ldx + k0, ldx, K - k0, base + SUB, wave, lane);
-    dma_subtile(x + m * ldx + k0 + 128, ldx, K - k0 - 128, base + 2 * SUB, wave, lane);
+    dma_rows64x128(dy + m * ldy + n0, ldy, N - n0, base, wave, lane);
+    dma_rows64x128(x + m * ldx + k0, ldx, K - k0, base + SUB, wave, lane);
+    dma_rows64x128(x + m * ldx + k0 + 128, ldx, K - k0 - 128, base + 2 * SUB, wave, lane);
   };
   auto compute = [&](int stage) {
     const char* ya = smem + stage * STAGE;
@@ -266,7 +221,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
 // token-major every MFMA operand of this product needs one; a 128 x 128 wave tile feeds 16 MFMAs
 // from 8 operand fragments (the 128 x 64 wave tile of wgrad2_kernel: 8 from 6), which moves the
 // LDS ceiling from about half to about three quarters of the MFMA rate. One workgroup per CU;
-// two 64 KiB stages, filled by LDS-DMA issued from inline assembly (see dma_subtile_asm) so that
+// two 64 KiB stages, filled by LDS-DMA issued from inline assembly (see dma_rows64x128_asm in mfma_tiles.h) so that
 // the transfer of tile t+1 stays in flight during the MFMAs of tile t.
 //
 // BIAS: the workgroups of the first K-tile column also sum their dY fragments over the tokens on the
@@ -302,14 +257,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = BIAS && tk == 0 && wk == 0;
 
-  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  const unsigned lds0 = (unsigned)(size_t)(dma_lptr_t)smem;
   auto issue = [&](int t, int stage) {
     const long long m = m_begin + (long long)t * 64;
     const unsigned base = lds0 + stage * STAGE;
-    dma_subtile_asm(dy + m * ldy + n0, ldy, 128, base, wave, lane);
-    dma_subtile_asm(dy + m * ldy + n0 + 128, ldy, 128, base + SUB, wave, lane);
-    dma_subtile_asm(x + m * ldx + k0, ldx, 128, base + 2 * SUB, wave, lane);
-    dma_subtile_asm(x + m * ldx + k0 + 128, ldx, 128, base + 3 * SUB, wave, lane);
+    dma_rows64x128_asm(dy + m * ldy + n0, ldy, 128, base, wave, lane);
+    dma_rows64x128_asm(dy + m * ldy + n0 + 128, ldy, 128, base + SUB, wave, lane);
+    dma_rows64x128_asm(x + m * ldx + k0, ldx, 128, base + 2 * SUB, wave, lane);
+    dma_rows64x128_asm(x + m * ldx + k0 + 128, ldx, 128, base + 3 * SUB, wave, lane);
   };
   if (ntiles > 0) issue(0, 0);
   for (int t = 0; t < ntiles; ++t) {

@@ -93,4 +93,69 @@ struct Stage64 {
   }
 };
 
+
+// ---- global -> LDS tile transfers (LDS-DMA: global_load_lds, 16 bytes per lane, no registers) --------
+// A piece is the 1 KiB that one wave instruction moves (64 lanes x 16 bytes, contiguous in LDS); the
+// XOR swizzle is applied on the global side: LDS slot `sl` of a row receives logical chunk swz(row, sl).
+typedef __attribute__((address_space(1))) const void* dma_gptr_t;
+typedef __attribute__((address_space(3))) void* dma_lptr_t;
+
+// [128 rows][64 cols] tile of a K-contiguous operand (128-byte rows, 16 pieces of 8 rows), 4 waves.
+// Rows at or past `row_limit` re-read row 0 (their results are never stored).
+__device__ __forceinline__ void dma_rows128x64(const bf16_t* g, long long ld, int row_limit, char* lds, int wave,
+                                               int lane) {
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int piece = wave * 4 + pc;
+    int row = piece * 8 + (lane >> 3);
+    const int chunk = swz<64>(row, lane & 7);
+    if (row >= row_limit) row = 0;
+    __builtin_amdgcn_global_load_lds((dma_gptr_t)(g + (long long)row * ld + chunk * 8),
+                                     (dma_lptr_t)(lds + piece * 1024), 16, 0, 0);
+  }
+}
+
+// [64 rows][128 cols] tile of a contraction-strided operand (256-byte rows, 16 pieces of 4 rows), 4
+// waves. Columns at or past `col_limit` re-read chunk 0 (never stored).
+__device__ __forceinline__ void dma_rows64x128(const bf16_t* g, long long ld, int col_limit, char* lds, int wave,
+                                               int lane) {
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int piece = wave * 4 + pc;
+    const int row = piece * 4 + (lane >> 4);
+    int chunk = swz<128>(row, lane & 15);
+    if (chunk * 8 >= col_limit) chunk = 0;
+    __builtin_amdgcn_global_load_lds((dma_gptr_t)(g + (long long)row * ld + chunk * 8),
+                                     (dma_lptr_t)(lds + piece * 1024), 16, 0, 0);
+  }
+}
+
+// The [64][128] transfer issued from inline assembly. hipcc treats an LDS-DMA builtin as an LDS write
+// that any later ds_read may alias and drains it (vmcnt(0)) before the next LDS read, which
+// serialises a multi-stage pipeline. Issued from asm the transfer is invisible to the compiler's
+// wait insertion and is retired by hand with s_waitcnt vmcnt before the barrier that publishes the
+// stage. M0 (LDS base of the piece) is written and restored inside the same statement.
+__device__ __forceinline__ void dma_rows64x128_asm(const bf16_t* g, long long ld, int col_limit, unsigned lds_addr,
+                                                   int wave, int lane) {
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int piece = wave * 4 + pc;
+    const int row = piece * 4 + (lane >> 4);
+    int chunk = swz<128>(row, lane & 15);
+    if (chunk * 8 >= col_limit) chunk = 0;
+    const bf16_t* src = g + (long long)row * ld + chunk * 8;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + piece * 1024);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+  }
+}
+
 }  // namespace dpa
