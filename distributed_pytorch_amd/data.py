@@ -9,8 +9,8 @@ device through pinned memory (reference: single-gpu/train.py:210-254). Two delib
   seeded identically on all ranks, and each rank keeps its own slice. A ``W``-rank run with
   micro-batch ``B`` therefore consumes exactly the windows of a 1-rank run with micro-batch
   ``W * B`` (the reference decorrelates ranks only through ``manual_seed(1729 + rank)``);
-* the next batch is assembled into a reusable pinned staging buffer and copied with
-  ``non_blocking=True`` so the host work overlaps queued GPU work.
+* the next batch is assembled into a reusable pinned staging buffer and copied on a dedicated
+  copy stream, so the host work and the transfer overlap the GPU work already queued.
 
 ``ensure_synthetic`` writes a synthetic token stream of the Shakespeare / TinyStories shape
 (GPT-2-BPE-like ids < vocab_size with a Zipf-like unigram distribution, EOT every few hundred
@@ -48,8 +48,12 @@ class DataLoader:
         self.gen.manual_seed(seed)
         self._pinned = None
         if self.device.type == "cuda":
+            # two pinned staging buffers and a copy stream of its own: the host-to-device transfer of the
+            # next batch runs beside the compute stream's kernels instead of queueing behind them
             self._pinned = [torch.empty(2, B, T, dtype=torch.long).pin_memory() for _ in range(2)]
+            self._copied = [None, None]       # event of the last transfer out of each staging buffer
             self._flip = 0
+            self._copy_stream = torch.cuda.Stream(device=self.device)
 
     def state_dict(self):
         return {"gen": self.gen.get_state()}
@@ -64,9 +68,13 @@ class DataLoader:
     def next_batch(self):
         B, T = self.B, self.T
         starts = self._starts()
+        slot = None
         if self._pinned is not None:
-            buf = self._pinned[self._flip]
+            slot = self._flip
+            buf = self._pinned[slot]
             self._flip ^= 1
+            if self._copied[slot] is not None:
+                self._copied[slot].synchronize()   # the transfer that last read this buffer has finished
         else:
             buf = torch.empty(2, B, T, dtype=torch.long)
         if self._native is not None:
@@ -78,7 +86,14 @@ class DataLoader:
                 arr[0, i] = w[:-1]
                 arr[1, i] = w[1:]
         if self.device.type == "cuda":
-            dev = buf.to(self.device, non_blocking=True)
+            with torch.cuda.stream(self._copy_stream):
+                dev = buf.to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+            self._copied[slot] = done
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)            # consumers on the compute stream are ordered after the copy
+            dev.record_stream(cur)          # the allocator must not recycle it while compute still reads it
             return dev[0], dev[1]
         return buf[0], buf[1]
 
