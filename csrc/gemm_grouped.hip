@@ -242,7 +242,7 @@ void gemm_grouped_wgrad(const void* a, long long lda, const void* b, long long l
   if (splits > max_s) splits = max_s;
   if (splits < 1) splits = 1;
   p.splits = splits;
-  if (splits > 1) hipMemsetAsync(out, 0, sizeof(float) * (size_t)ngroups * N * K, st);
+  if (splits > 1) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)ngroups * N * K, st);
   const dim3 grid(tiles * splits, ngroups), block(256);
   hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, grid, block, (size_t)(2 * 64 * 128 * 2), st, p);
 }
