@@ -121,13 +121,9 @@ class GQA(nn.Module):
 
 def _mla_attention(q_eff, k_eff, v_lat, scale, dropout_p):
     """Multi-query attention over latent keys/values: q_eff [B,T,nh,Dk], k_eff [B,Tk,1,Dk],
-    v_lat [B,Tk,1,Dv] -> [B,T,nh,Dv]. Uses the flash kernel when Dk is a supported head size
-    (V is zero-padded to Dk), otherwise the eager path."""
-    Dk, Dv = q_eff.shape[-1], v_lat.shape[-1]
-    if q_eff.is_cuda and q_eff.dtype == torch.bfloat16 and Dk in (64, 128) and dropout_p == 0.0:
-        v_pad = v_lat if Dv == Dk else F.pad(v_lat, (0, Dk - Dv))
-        return ops.causal_attention(q_eff.contiguous(), k_eff.contiguous(), v_pad.contiguous(), scale)[..., :Dv]
-    return ops.causal_attention_eager(q_eff, k_eff, v_lat, scale, dropout_p)
+    v_lat [B,Tk,1,Dv] -> [B,T,nh,Dv]. Key widths up to 128 run on the flash kernels (features are
+    zero-padded to 64 or 128 inside ``ops.causal_attention``), wider ones on the eager path."""
+    return ops.causal_attention(q_eff, k_eff, v_lat, scale, dropout_p)
 
 
 class NaiveMHLA(nn.Module):

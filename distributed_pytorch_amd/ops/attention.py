@@ -25,7 +25,15 @@ from .._ext import ops, use_hip
 
 def _hip_ok(q, k, v) -> bool:
     return (use_hip(q, k, v) and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16
-            and v.dtype == torch.bfloat16 and q.shape[-1] in (64, 128) and q.shape[1] >= 1)
+            and v.dtype == torch.bfloat16 and q.shape[-1] in (64, 128) and k.shape[-1] == q.shape[-1]
+            and v.shape[-1] == q.shape[-1] and q.shape[1] >= 1)
+
+
+def _paddable(q, k, v) -> bool:
+    """bf16 GPU tensors whose head sizes are not native to the kernels but fit after zero padding."""
+    return (use_hip(q, k, v) and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16
+            and q.shape[-1] == k.shape[-1] and max(q.shape[-1], v.shape[-1]) <= 128 and q.shape[1] >= 1
+            and k.shape[2] == v.shape[2] and q.shape[2] % k.shape[2] == 0)
 
 
 def _packed(t: torch.Tensor) -> torch.Tensor:
@@ -131,4 +139,12 @@ def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
         scale = 1.0 / math.sqrt(q.shape[-1])
     if dropout_p == 0.0 and _hip_ok(q, k, v):
         return _FlashAttnFn.apply(q, k, v, float(scale))
+    if dropout_p == 0.0 and _paddable(q, k, v):
+        # Other head sizes up to 128 run on the flash kernels too: zero features change neither the
+        # scores (the scale is explicit) nor the kept output columns, and no T x T matrix is formed.
+        hs, dv = q.shape[-1], v.shape[-1]
+        tgt = 64 if max(hs, dv) <= 64 else 128
+        qp, kp = F.pad(q, (0, tgt - hs)), F.pad(k, (0, tgt - hs))
+        vp = F.pad(v, (0, tgt - dv))
+        return _FlashAttnFn.apply(qp, kp, vp, float(scale))[..., :dv]
     return causal_attention_eager(q, k, v, float(scale), dropout_p)

@@ -535,3 +535,25 @@ def test_dense_plan_scatter_and_combine(N, E, k, C):
     got, want = run(False), run(True)
     for a, b in zip(got, want):
         assert rel_err(a, b) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,Tq,Tk,nh,nkv,hs,dv", [(2, 256, 256, 8, 8, 32, 32), (2, 200, 200, 4, 1, 48, 32),
+                                                  (1, 128, 128, 4, 2, 96, 96), (2, 1, 130, 4, 4, 32, 32)])
+def test_flash_attention_padded_head_sizes(B, Tq, Tk, nh, nkv, hs, dv):
+    """Head sizes that are not native to the kernels (and a value width below the key width) run on
+    them after zero padding and match the eager statement, forward and backward."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    q = torch.randn(B, Tq, nh, hs, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(B, Tk, nkv, hs, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(B, Tk, nkv, dv, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    do = torch.randn(B, Tq, nh, dv, device=DEV, dtype=torch.bfloat16)
+    scale = 1.0 / math.sqrt(hs)
+    o = ops.causal_attention(q, k, v, scale)
+    o.backward(do)
+    qr, kr, vr = [t.detach().float().requires_grad_() for t in (q, k, v)]
+    orf = ops.causal_attention_eager(qr, kr, vr, scale)
+    orf.backward(do.float())
+    assert o.shape == (B, Tq, nh, dv)
+    assert rel_err(o, orf) < 1e-2
+    assert rel_err(q.grad, qr.grad) < 2e-2 and rel_err(k.grad, kr.grad) < 2e-2 and rel_err(v.grad, vr.grad) < 2e-2

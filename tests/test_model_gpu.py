@@ -17,6 +17,8 @@ VARIANTS = {
     "mqa_sin": dict(attn="mqa", pos_emb="sin", non_linearity="relu"),
     "mla_rope_flash": dict(attn="mla", pos_emb="rope", q_latent_dim=64, kv_latent_dim=96, rope_head_dim=32),
     "mla_naive_flash": dict(attn="mla", pos_emb="learn", q_latent_dim=64, kv_latent_dim=64),
+    "mla_rope_small_latent": dict(attn="mla", pos_emb="rope", q_latent_dim=32, kv_latent_dim=32, rope_head_dim=16),
+    "mha_hs32": dict(attn="mha", n_head=8, pos_emb="learn", non_linearity="gelu"),
     "moe": dict(attn="mha", pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2),
     "recompute": dict(attn="mha", pos_emb="learn", non_linearity="gelu", act_recomp=True),
     "recompute_block": dict(attn="mha", pos_emb="learn", non_linearity="gelu", act_recomp=True,
@@ -34,7 +36,7 @@ def test_extension_loaded():
 def test_bf16_hip_matches_fp32_eager(name):
     from distributed_pytorch_amd.parallel.engine import Engine
     torch.manual_seed(0)
-    cfg = LLMconfig(**BASE, **VARIANTS[name]).finalize()
+    cfg = LLMconfig(**{**BASE, **VARIANTS[name]}).finalize()
     ref = LLM(cfg)
     sd = {k: v.clone() for k, v in ref.state_dict().items()}
     idx = torch.randint(0, cfg.vocab_size, (4, 256))
