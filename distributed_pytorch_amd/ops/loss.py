@@ -125,6 +125,11 @@ def linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor
 
 
 # ---------------------------------------------------------------------------------------------
+def _comm():
+    from ..parallel import comm   # imported late: ops must stay importable without the parallel package
+    return comm
+
+
 class _VocabParallelXentFn(torch.autograd.Function):
     """logits_local [N, V/W] holds columns [vocab_start, vocab_start + V/W) of the full logits."""
 
@@ -146,10 +151,10 @@ class _VocabParallelXentFn(torch.autograd.Function):
             tg = torch.where(inr, work.gather(1, loc.clamp(0, work.shape[1] - 1)[:, None])[:, 0],
                              torch.zeros_like(mx))
         gmx = mx.clone()
-        dist.all_reduce(gmx, op=dist.ReduceOp.MAX, group=group)
+        _comm().all_reduce(gmx, op=dist.ReduceOp.MAX, group=group)
         sm = sm * torch.exp(mx - gmx)
         packed = torch.stack([sm, tg])
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        _comm().all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         lse = gmx + torch.log(packed[0])
         tgt_logit = packed[1].contiguous()
         valid = targets != ignore_index

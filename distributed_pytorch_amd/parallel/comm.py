@@ -55,8 +55,18 @@ def configure_rccl_env():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 
+def arm_hang_dump():
+    """DPA_HANG_DUMP_S=<seconds>: every that many seconds each rank writes the Python stack of all its
+    threads to stderr. A job stuck in a collective then shows, per rank, which call it is waiting in."""
+    secs = float(os.environ.get("DPA_HANG_DUMP_S", "0") or 0)
+    if secs > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(secs, repeat=True)
+
+
 def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistInfo:
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    arm_hang_dump()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,10 +120,21 @@ def _count(kind: str, t: torch.Tensor):
     STATS[kind] += t.numel() * t.element_size()
 
 
+def _staged(t: torch.Tensor, group) -> bool:
+    """gloo with GPU tensors (several ranks rehearsing on one GPU): the transport runs on a host copy,
+    synchronously. gloo's own device-tensor path does not complete on this ROCm stack."""
+    return t.is_cuda and _backend(group) == "gloo"
+
+
 def all_reduce(t: torch.Tensor, op=None, group=None, async_op: bool = False):
     if _single(group):
         return _Done()
     _count("all_reduce", t)
+    if _staged(t, group):
+        h = t.float().cpu() if t.dtype == torch.bfloat16 else t.cpu()
+        dist.all_reduce(h, op=op or dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
     w = dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=async_op)
     return w if async_op else _Done()
 
@@ -122,6 +143,11 @@ def broadcast(t: torch.Tensor, src: int = 0, group=None, async_op: bool = False)
     if _single(group):
         return _Done()
     _count("broadcast", t)
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return _Done()
     w = dist.broadcast(t, src=src, group=group, async_op=async_op)
     return w if async_op else _Done()
 
@@ -136,7 +162,7 @@ def reduce_scatter(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: b
     _count("reduce_scatter", inp)
     if _backend(group) == "gloo":
         # gloo has no reduce-scatter: sum everything, keep the local slice (tests only)
-        tmp = inp.clone()
+        tmp = inp.float().cpu() if inp.is_cuda else inp.clone()
         dist.all_reduce(tmp, group=group)
         n = out.numel()
         r = get_rank(group)
@@ -157,8 +183,9 @@ def all_gather(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool 
     _count("all_gather", out)
     if _backend(group) == "gloo":
         n = inp.numel()
-        parts = [torch.empty_like(inp) for _ in range(W)]
-        dist.all_gather(parts, inp.clone(), group=group)
+        src = inp.cpu() if inp.is_cuda else inp.clone()
+        parts = [torch.empty_like(src) for _ in range(W)]
+        dist.all_gather(parts, src, group=group)
         for r, p in enumerate(parts):
             out[r * n:(r + 1) * n].copy_(p)
         return _Done()
@@ -173,6 +200,19 @@ def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=
         out.copy_(inp)
         return _Done()
     _count("all_to_all", inp)
+    if _staged(inp, group):
+        # gloo has no all-to-all on device tensors: gather every rank's rows on the host, keep ours
+        W, r = world_size(group), get_rank(group)
+        src = inp.cpu()
+        ins = list(in_splits) if in_splits is not None else [inp.shape[0] // W] * W
+        everyone = [None] * W
+        dist.all_gather_object(everyone, (src, ins), group=group)
+        rows = []
+        for peer_rows, peer_splits in everyone:
+            start = sum(peer_splits[:r])
+            rows.append(peer_rows[start:start + peer_splits[r]])
+        out.copy_(torch.cat(rows, 0))
+        return _Done()
     w = dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
     return w if async_op else _Done()
 
