@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from distributed_pytorch_amd.config import PRESETS, LLMconfig, Trainconfig  # noqa: E402
-from distributed_pytorch_amd.data import DataLoader, ensure_synthetic  # noqa: E402
+from distributed_pytorch_amd.data import DataLoader, check_vocab, ensure_synthetic  # noqa: E402
 from distributed_pytorch_amd.models.llm import LLM  # noqa: E402
 from distributed_pytorch_amd.parallel import comm  # noqa: E402
 from distributed_pytorch_amd.trainer import build_engine, get_lr  # noqa: E402
@@ -78,7 +78,8 @@ def main():
                      max_iters=args.steps + args.warmup, learning_rate=3e-4, warmup_steps=10, grad_clip=1.0,
                      bucket_mb=args.bucket_mb, dtype="bf16")
 
-    data_dir = ensure_synthetic(os.path.join("/tmp", "dpa_bench_data"), 1 << 24, mc.vocab_size, info.rank)
+    data_dir = ensure_synthetic(os.path.join("/tmp", f"dpa_bench_data_v{mc.vocab_size}"), 1 << 24, mc.vocab_size, info.rank)
+    check_vocab(os.path.join(data_dir, "train.bin"), mc.vocab_size)
     loader = DataLoader(B, T, os.path.join(data_dir, "train.bin"), info.device, info.rank, world, 1729)
 
     model = LLM(mc)

@@ -241,7 +241,7 @@ Tensor embed_fwd(const Tensor& idx, const Tensor& wte, const std::optional<Tenso
   }
   Tensor out = at::empty({idx.size(0), T, C}, wte.options());
   dpa::embed_fwd((const long long*)idx.data_ptr<int64_t>(), wte.data_ptr(), opt_ptr(pos), out.data_ptr(),
-                 idx.numel(), (int)T, (int)pos0, (int)C, is_bf16(wte), cur_stream());
+                 idx.numel(), (int)T, (int)pos0, (int)C, wte.size(0), is_bf16(wte), cur_stream());
   return out;
 }
 
@@ -256,7 +256,7 @@ void embed_bwd(const Tensor& dout, const Tensor& ids_sorted, const Tensor& perm,
   Tensor scratch = at::empty({2 * (int64_t)dpa::embed_bwd_chunks(N) * C}, dwte.options().dtype(at::kFloat));
   dpa::embed_bwd(dout.data_ptr(), (const long long*)ids_sorted.data_ptr<int64_t>(),
                  (const long long*)perm.data_ptr<int64_t>(), dwte.data_ptr(), scratch.data_ptr<float>(), N, (int)C,
-                 is_bf16(dwte), cur_stream());
+                 dwte.size(0), is_bf16(dwte), cur_stream());
 }
 
 void pos_bwd(const Tensor& dout, Tensor dpos, int64_t pos0) {

@@ -9,6 +9,9 @@
 // a rare one.
 // Backward (learned position table): dpos[t, :] += sum_b dout[b, t, :].
 //
+// Token ids are data: an id outside [0, V) (a corrupt shard, a data file of another vocabulary) reads
+// as a zero embedding row and receives no gradient; it can never become an out-of-bounds access.
+//
 // Replaces `nn.Embedding` forward/backward (reference: single-gpu/model.py:541-543,652-666).
 #include "common.h"
 #include "kernels.h"
@@ -18,15 +21,16 @@ namespace dpa {
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ idx, const T* __restrict__ wte,
                                                         const T* __restrict__ pos, T* __restrict__ out, long long N,
-                                                        int T_len, int pos0, int C) {
+                                                        int T_len, int pos0, int C, long long V) {
   const int nvec = C >> 3;
   const long long total = N * nvec;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / nvec;
     const int c = (int)(i - n * nvec) * 8;
-    float a[8];
-    load8(wte + (size_t)idx[n] * C + c, a);
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long id = idx[n];
+    if (id >= 0 && id < V) load8(wte + (size_t)id * C + c, a);
     if (pos != nullptr) {
       float p[8];
       load8(pos + (size_t)(pos0 + (int)(n % T_len)) * C + c, p);
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const T* __restric
                                                               const long long* __restrict__ ids,
                                                               const long long* __restrict__ perm,
                                                               T* __restrict__ dwte, float* __restrict__ head,
-                                                              float* __restrict__ tail, long long N, int C) {
+                                                              float* __restrict__ tail, long long N, int C,
+                                                              long long V) {
   const long long s = (long long)blockIdx.x * kEmbChunk;
   const long long e = (s + kEmbChunk < N) ? s + kEmbChunk : N;
   const bool cont_prev = s > 0 && ids[s - 1] == ids[s];
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const T* __restric
           store8(head + (size_t)blockIdx.x * C + cv * 8, acc);
         } else if (j == e && cont_next) {
           store8(tail + (size_t)blockIdx.x * C + cv * 8, acc);
-        } else {
+        } else if (tok >= 0 && tok < V) {
           float g[8];
           load8(dwte + (size_t)tok * C + cv * 8, g);
 #pragma unroll
@@ -94,12 +99,13 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const T* __restric
 template <typename T>
 __global__ __launch_bounds__(128) void embed_bwd_fix_kernel(const long long* __restrict__ ids, T* __restrict__ dwte,
                                                             const float* __restrict__ head,
-                                                            const float* __restrict__ tail, long long N, int C) {
+                                                            const float* __restrict__ tail, long long N, int C,
+                                                            long long V) {
   const long long s = (long long)blockIdx.x * kEmbChunk;
   const long long e = (s + kEmbChunk < N) ? s + kEmbChunk : N;
   const long long tok = ids[e - 1];
   const bool cont_next = e < N && ids[e] == tok;
-  if (!cont_next) return;
+  if (!cont_next || tok < 0 || tok >= V) return;
   const bool whole = ids[s] == tok;  // the chunk is a single run
   if (whole && s > 0 && ids[s - 1] == tok) return;  // the run started in an earlier chunk
   long long lo = e, hi = N;  // first position > e-1 whose id differs from tok
@@ -155,21 +161,21 @@ static int ew_grid(long long nthreads) {
 }
 
 void embed_fwd(const long long* idx, const void* wte, const void* pos, void* out, long long N, int T_len, int pos0,
-               int C, bool is_bf16, hipStream_t st) {
+               int C, long long V, bool is_bf16, hipStream_t st) {
   if (N == 0) return;
   const dim3 grid(ew_grid(N * (C >> 3))), block(256);
   if (is_bf16)
     hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), grid, block, 0, st, idx, (const bf16_t*)wte, (const bf16_t*)pos,
-                       (bf16_t*)out, N, T_len, pos0, C);
+                       (bf16_t*)out, N, T_len, pos0, C, V);
   else
     hipLaunchKernelGGL((embed_fwd_kernel<float>), grid, block, 0, st, idx, (const float*)wte, (const float*)pos,
-                       (float*)out, N, T_len, pos0, C);
+                       (float*)out, N, T_len, pos0, C, V);
 }
 
 int embed_bwd_chunks(long long N) { return (int)((N + kEmbChunk - 1) / kEmbChunk); }
 
 void embed_bwd(const void* dout, const long long* ids_sorted, const long long* perm, void* dwte, float* scratch,
-               long long N, int C, bool is_bf16, hipStream_t st) {
+               long long N, int C, long long V, bool is_bf16, hipStream_t st) {
   if (N == 0) return;
   const int nch = embed_bwd_chunks(N);
   float* head = scratch;
@@ -177,12 +183,12 @@ void embed_bwd(const void* dout, const long long* ids_sorted, const long long* p
   const dim3 grid(nch), block(128);
   if (is_bf16) {
     hipLaunchKernelGGL((embed_bwd_chunk_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids_sorted, perm,
-                       (bf16_t*)dwte, head, tail, N, C);
-    hipLaunchKernelGGL((embed_bwd_fix_kernel<bf16_t>), grid, block, 0, st, ids_sorted, (bf16_t*)dwte, head, tail, N, C);
+                       (bf16_t*)dwte, head, tail, N, C, V);
+    hipLaunchKernelGGL((embed_bwd_fix_kernel<bf16_t>), grid, block, 0, st, ids_sorted, (bf16_t*)dwte, head, tail, N, C, V);
   } else {
     hipLaunchKernelGGL((embed_bwd_chunk_kernel<float>), grid, block, 0, st, (const float*)dout, ids_sorted, perm,
-                       (float*)dwte, head, tail, N, C);
-    hipLaunchKernelGGL((embed_bwd_fix_kernel<float>), grid, block, 0, st, ids_sorted, (float*)dwte, head, tail, N, C);
+                       (float*)dwte, head, tail, N, C, V);
+    hipLaunchKernelGGL((embed_bwd_fix_kernel<float>), grid, block, 0, st, ids_sorted, (float*)dwte, head, tail, N, C, V);
   }
 }
 

@@ -35,10 +35,10 @@ void xent(int mode, void* logits, bool is_bf16, const long long* targets, float*
 
 // ---- Embedding -------------------------------------------------------------------------
 void embed_fwd(const long long* idx, const void* wte, const void* pos, void* out, long long N, int T_len, int pos0,
-               int C, bool is_bf16, hipStream_t st);
+               int C, long long V, bool is_bf16, hipStream_t st);
 int embed_bwd_chunks(long long N);  // scratch = 2 * chunks * C floats
 void embed_bwd(const void* dout, const long long* ids_sorted, const long long* perm, void* dwte, float* scratch,
-               long long N, int C, bool is_bf16, hipStream_t st);
+               long long N, int C, long long V, bool is_bf16, hipStream_t st);
 void pos_bwd(const void* dout, void* dpos, int B, int T_len, int pos0, int C, bool is_bf16, hipStream_t st);
 
 // ---- Activations -----------------------------------------------------------------------

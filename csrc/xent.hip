@@ -129,7 +129,8 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
       return;
     }
     lse = mx + __logf(sum);
-    if (threadIdx.x == 0) loss_rows[row] = lse - Cvt<T>::ld(lr + tloc);
+    // a target outside this shard's columns (corrupt label) reads as logit 0 instead of out of bounds
+    if (threadIdx.x == 0) loss_rows[row] = lse - ((tloc >= 0 && tloc < V) ? Cvt<T>::ld(lr + tloc) : 0.f);
   } else {
     lse = lse_in[row];
     if (threadIdx.x == 0 && loss_rows != nullptr) {

@@ -113,17 +113,42 @@ def synthetic_tokens(n: int, vocab_size: int, seed: int = 1729) -> np.ndarray:
     return toks
 
 
+def check_vocab(file_path: str, vocab_size: int, probe_tokens: int = 1 << 22):
+    """Fail early, on the host, when a token file holds ids the model has no row for (a file tokenised
+    for another vocabulary). Probes the head and the tail of the file, not all of it."""
+    tokens = np.memmap(file_path, dtype=np.uint16, mode="r")
+    n = len(tokens)
+    top = int(tokens[:min(n, probe_tokens)].max()) if n else 0
+    if n > probe_tokens:
+        top = max(top, int(tokens[n - probe_tokens:].max()))
+    if top >= vocab_size:
+        raise ValueError(f"{file_path}: token id {top} does not fit vocab_size {vocab_size}; "
+                         "the data was tokenised for another vocabulary")
+
+
 def ensure_synthetic(data_dir: str, n_tokens: int, vocab_size: int, rank: int = 0, seed: int = 1729) -> str:
-    """Create ``train.bin`` / ``val.bin`` under ``data_dir`` if missing. Returns ``data_dir``."""
+    """Create ``train.bin`` / ``val.bin`` under ``data_dir`` if missing or made for another vocabulary,
+    size or seed (a sidecar ``synthetic.json`` records what the files hold). Returns ``data_dir``."""
+    import json
     d = Path(data_dir)
     if rank == 0:
         d.mkdir(parents=True, exist_ok=True)
+        want = {"vocab_size": int(vocab_size), "n_tokens": int(n_tokens), "seed": int(seed)}
+        meta = d / "synthetic.json"
+        try:
+            have = json.loads(meta.read_text())
+        except (OSError, ValueError):
+            have = None
         for name, n, sd in (("train.bin", n_tokens, seed), ("val.bin", max(n_tokens // 10, 4096), seed + 1)):
             f = d / name
-            if not f.exists() or f.stat().st_size != 2 * n:
+            if have != want or not f.exists() or f.stat().st_size != 2 * n:
                 tmp = d / (name + f".tmp{os.getpid()}")
                 synthetic_tokens(n, vocab_size, sd).tofile(tmp)
                 os.replace(tmp, f)
+        if have != want:
+            tmp = d / f"synthetic.json.tmp{os.getpid()}"
+            tmp.write_text(json.dumps(want))
+            os.replace(tmp, meta)
     comm.barrier()
     return str(d)
 

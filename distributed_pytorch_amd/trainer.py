@@ -24,7 +24,7 @@ import torch
 
 from .checkpoint import load_resume, save_reference_checkpoint, save_resume
 from .config import LLMconfig, Trainconfig
-from .data import DataLoader, ensure_synthetic, resolve_data_dir
+from .data import DataLoader, check_vocab, ensure_synthetic, resolve_data_dir
 from .models.llm import LLM
 from .parallel import comm
 from .utils.metrics import JsonlSink, PEAK_BF16_DENSE_FLOPS, mfu, model_flops_per_token
@@ -109,6 +109,8 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         data_dir = ensure_synthetic(data_dir, n, mc.vocab_size, info.rank, tc.seed)
     say(f"Using Dataset {os.path.basename(data_dir)}")
     B, T = tc.batch_size, mc.block_size
+    for split in ("train.bin", "val.bin"):
+        check_vocab(os.path.join(data_dir, split), mc.vocab_size)
     train_loader = DataLoader(B, T, os.path.join(data_dir, "train.bin"), device, info.rank, info.world_size, tc.seed)
     val_loader = DataLoader(B, T, os.path.join(data_dir, "val.bin"), device, info.rank, info.world_size, tc.seed + 7)
 

@@ -77,3 +77,19 @@ def test_resume_continues_identically(tmp_path):
     tc, mc = configs_from_args((base + f" --max_iters 6 --resume {tmp_path / 'b_resume'} --file_name {tmp_path / 'c'}").split())
     resumed = train(tc, mc, "single")
     assert resumed["losses"] == pytest.approx(full["losses"][5:], rel=1e-5)
+
+
+def test_synthetic_data_is_rebuilt_for_another_vocabulary(tmp_path):
+    """A token file made for a larger vocabulary must never reach a smaller model: the synthetic
+    files are regenerated when the vocabulary changes, and check_vocab refuses a foreign file."""
+    import numpy as np
+    from distributed_pytorch_amd.data import check_vocab
+    d = ensure_synthetic(str(tmp_path / "syn"), 20000, 50304)
+    big = np.fromfile(os.path.join(d, "train.bin"), dtype=np.uint16)
+    assert big.max() >= 1000
+    with pytest.raises(ValueError):
+        check_vocab(os.path.join(d, "train.bin"), 65)
+    d = ensure_synthetic(str(tmp_path / "syn"), 20000, 65)
+    small = np.fromfile(os.path.join(d, "train.bin"), dtype=np.uint16)
+    assert small.max() < 65 and len(small) == 20000
+    check_vocab(os.path.join(d, "train.bin"), 65)

@@ -557,3 +557,32 @@ def test_flash_attention_padded_head_sizes(B, Tq, Tk, nh, nkv, hs, dv):
     assert o.shape == (B, Tq, nh, dv)
     assert rel_err(o, orf) < 1e-2
     assert rel_err(q.grad, qr.grad) < 2e-2 and rel_err(k.grad, kr.grad) < 2e-2 and rel_err(v.grad, vr.grad) < 2e-2
+
+
+def test_out_of_range_ids_and_targets_are_contained():
+    """Token ids / labels outside the vocabulary (a corrupt shard) read as a zero embedding row, get
+    no gradient and never index out of bounds; the rest of the batch is unaffected."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    V, C, B, T = 512, 256, 4, 64
+    wte = torch.randn(V, C, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    idx = torch.randint(0, V, (B, T), device=DEV)
+    bad = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    bad[0, 3] = bad[1, 10] = bad[3, 63] = True
+    idx_bad = idx.clone()
+    idx_bad[0, 3], idx_bad[1, 10], idx_bad[3, 63] = V + 7, -5, 60000
+    out = ops.embedding(idx_bad, wte)
+    do = torch.randn_like(out)
+    out.backward(do)
+    ref_w = wte.detach().float().requires_grad_()
+    ref = torch.nn.functional.embedding(idx, ref_w) * (~bad)[..., None]
+    ref.backward(do.float())
+    assert torch.equal(out[bad], torch.zeros_like(out[bad]))
+    assert rel_err(out, ref) < 1e-3 and rel_err(wte.grad, ref_w.grad) < 1e-2
+    # labels: an out-of-range target is finite and leaves the other rows' loss gradient intact
+    logits = torch.randn(256, V, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    tgt = torch.randint(0, V, (256,), device=DEV)
+    tgt[5] = V + 100
+    loss = ops.cross_entropy(logits, tgt)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(logits.grad).all()
