@@ -652,6 +652,38 @@ std::tuple<Tensor, Tensor> wgrad2_slabs_bias(const Tensor& dy, const Tensor& x) 
   return {slabs, colsum(dy)};
 }
 
+// dw_acc [N, K] += dy^T x and, when given, db_acc [N] += column sums of dy: the weight-gradient GEMM
+// and the folds of its per-split slabs, with both results accumulated in place (bf16 or fp32
+// destinations, typically views of a flat gradient buffer).
+void wgrad2_direct(const Tensor& dy, const Tensor& x, Tensor dw_acc, const std::optional<Tensor>& db_acc) {
+  check_rows2d(dy, "dy");
+  check_rows2d(x, "x");
+  const int64_t M = dy.size(0), N = dy.size(1), K = x.size(1);
+  TORCH_CHECK(x.size(0) == M && dpa::wgrad2_ok((int)M, (int)N, (int)K), "wgrad2: unsupported shape ", M, "x", N, "x", K);
+  check_act(dw_acc, "dw_acc");
+  TORCH_CHECK(dw_acc.numel() == N * K, "wgrad2_direct: dw_acc must hold N*K elements");
+  if (db_acc.has_value()) {
+    check_act(*db_acc, "db_acc");
+    TORCH_CHECK(db_acc->numel() == N && N % 8 == 0, "wgrad2_direct: db_acc must hold N elements (N % 8 == 0)");
+  }
+  const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
+  Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
+  if (db_acc.has_value() && dpa::wgrad2_fuses_bias((int)M, (int)N, (int)K)) {
+    Tensor bslabs = at::empty({splits, N}, dy.options().dtype(at::kFloat));
+    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                     x.stride(0), splits, cur_stream(), bslabs.data_ptr<float>());
+    dpa::wgrad_finish(bslabs.data_ptr<float>(), db_acc->data_ptr(), N, splits, true, is_bf16(*db_acc), cur_stream());
+  } else {
+    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
+                     x.stride(0), splits, cur_stream());
+    if (db_acc.has_value()) {
+      Tensor cs = colsum(dy);
+      dpa::wgrad_finish(cs.data_ptr<float>(), db_acc->data_ptr(), N, 1, true, is_bf16(*db_acc), cur_stream());
+    }
+  }
+  dpa::wgrad_finish(slabs.data_ptr<float>(), dw_acc.data_ptr(), N * K, splits, true, is_bf16(dw_acc), cur_stream());
+}
+
 // dst_g (+)= ws[g] for every g: ws fp32 [G, ...], dst_ptrs int64 [G] device addresses of equally sized,
 // 16-byte aligned destinations (checked by the caller, which owns the tensors behind the addresses).
 void ws_to_many(const Tensor& ws, const Tensor& dst_ptrs, bool accumulate, bool out_bf16) {
@@ -670,6 +702,7 @@ void ws_to_many(const Tensor& ws, const Tensor& dst_ptrs, bool accumulate, bool 
 TORCH_LIBRARY(dpa, m) {
   m.def("ws_to_many(Tensor ws, Tensor dst_ptrs, bool accumulate, bool out_bf16) -> ()");
   m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
+  m.def("wgrad2_direct(Tensor dy, Tensor x, Tensor(a!) dw_acc, Tensor(b!)? db_acc) -> ()");
   m.def("moe_topk_gate(Tensor logits, Tensor? bias, int k) -> (Tensor, Tensor)");
   m.def("moe_plan(Tensor idx, int n_experts, int rows) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("grouped_gemm(Tensor a, Tensor w_ptrs, int w_rows, int w_cols, bool w_is_kn, Tensor block_group) -> Tensor");
@@ -716,6 +749,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("ws_to_many", ws_to_many);
   m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);
+  m.impl("wgrad2_direct", wgrad2_direct);
   m.impl("moe_topk_gate", moe_topk_gate);
   m.impl("moe_plan", moe_plan);
   m.impl("grouped_gemm", grouped_gemm);

@@ -86,12 +86,24 @@ def _direct_target(w_param, dy2, x2):
     return g if (wgrad2_supported(dy2, x2) and not _library_wgrad(dy2, x2)) else None
 
 
+def _direct_bias_target(b_param):
+    """The flat-buffer gradient view of a bias that asked for direct accumulation, else None."""
+    if b_param is None or not getattr(b_param, "_dpa_direct", False):
+        return None
+    g = b_param.grad
+    if g is None or g.dtype not in (torch.bfloat16, torch.float32) or not g.is_contiguous() \
+            or g.data_ptr() % 16 != 0 or g.numel() % 8 != 0:
+        return None
+    return g
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, sole_use):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.w_param = w if sole_use else None
+        ctx.b_param = b if sole_use else None
         return F.linear(x, w, b)
 
     @staticmethod
@@ -111,12 +123,14 @@ class _LinearFn(torch.autograd.Function):
             # of convert + autograd's accumulate). Returning None for dw still runs the parameter's
             # AccumulateGrad node, so post-accumulate hooks (bucket / unit accounting of the
             # engines) fire exactly as they do for an autograd-accumulated gradient.
-            if need_b:
+            btarget = _direct_bias_target(ctx.b_param) if need_b else None
+            if need_b and btarget is None:
                 slabs, dbf = ops().wgrad2_slabs_bias(dy2, x2)
                 db = dbf.to(dy2.dtype)
+                ops().ws_to(slabs, target, True)
             else:
-                slabs = ops().wgrad2_slabs(dy2, x2)
-            ops().ws_to(slabs, target, True)
+                # GEMM + folds of the weight and bias slabs into the flat buffers: one op, no temporaries
+                ops().wgrad2_direct(dy2, x2, target, btarget)
         elif ctx.needs_input_grad[1]:
             if wgrad2_supported(dy2, x2) or wgrad_supported(dy2, x2):
                 dw, db = weight_grad(dy2, x2, need_b)

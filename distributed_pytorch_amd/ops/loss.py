@@ -93,7 +93,8 @@ class _LinearXentFn(torch.autograd.Function):
                 torch.mm(lg, w, out=dx[r0:r1])
             if need_dw:
                 if use_wg:
-                    ws.add_(torch.mm(lg.t(), xc))
+                    # bf16 operands, fp32 sum: the library GEMM reads and writes the accumulator itself
+                    torch.addmm(ws, lg.t(), xc, out_dtype=torch.float32, out=ws)
                 elif dw is None:
                     dw = torch.mm(lg.t(), xc)
                 else:

@@ -123,9 +123,11 @@ class Engine(nn.Module):
         ln_params = set()
         if os.environ.get("DPA_DIRECT_LN", "1") == "1":
             ln_params = {id(p) for m in self.module.modules() if isinstance(m, nn.LayerNorm) for p in m.parameters()}
+            ln_params |= {id(m.bias) for m in self.module.modules() if isinstance(m, nn.Linear) and m.bias is not None}
         for g in self.groups:
             for s in g.slots:
-                if s.param.dim() == 2 or id(s.param) in ln_params:   # weight matrices; LayerNorm gamma / beta
+                # weight matrices; LayerNorm gamma / beta; Linear biases
+                if s.param.dim() == 2 or id(s.param) in ln_params:
                     s.param._dpa_direct = True
 
     def _opt_range(self, g: FlatGroup):

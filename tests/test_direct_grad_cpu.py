@@ -26,6 +26,12 @@ class _FakeHip:
         return (dy2.float().t() @ x2.float()).unsqueeze(0), dy2.float().sum(0)
 
     @staticmethod
+    def wgrad2_direct(dy2, x2, dw_acc, db_acc):
+        dw_acc.add_((dy2.float().t() @ x2.float()).to(dw_acc.dtype).view_as(dw_acc))
+        if db_acc is not None:
+            db_acc.add_(dy2.float().sum(0).to(db_acc.dtype))
+
+    @staticmethod
     def wgrad2(dy2, x2):
         return (dy2.float().t() @ x2.float()).to(dy2.dtype)
 
