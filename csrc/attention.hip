@@ -21,6 +21,7 @@
 //
 // Replaces `F.scaled_dot_product_attention(is_causal=True)` and the `repeat_interleave` GQA
 // expansion of the reference (reference: single-gpu/model.py:144-149).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -58,6 +59,25 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDefer = 6.0f;   // deferred-rescale threshold of the forward, in log2 units
 
+// Which (tile rank, batch*head) a workgroup works on. rank 0 is the heaviest tile of its head.
+// group == 0: rank-major over all heads (all heaviest tiles first). group == G: workgroups are
+// re-labelled so that each XCD (own L2) owns a contiguous run of heads, and inside it the tiles of G
+// heads at a time run rank-major: all tiles that read one head's K/V (or Q/dO) are in flight
+// together on one XCD and share the operand through its L2, while the heavy-first order inside a
+// group keeps the tail short.
+__device__ __forceinline__ void tile_order(int bid, int nwg, int ntile, int BH, int group, int& rank, int& bh) {
+  if (group <= 0 || BH % group != 0) {
+    rank = bid / BH;
+    bh = bid % BH;
+    return;
+  }
+  const int id = xcd_remap(bid, nwg);
+  const int per = group * ntile;
+  const int grp = id / per, rem = id % per;
+  rank = rem / group;
+  bh = grp * group + rem % group;
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
@@ -68,8 +88,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int BH = p.B * p.nh;
   const int nqt = (p.Tq + 127) / 128;
-  const int qt = nqt - 1 - (int)blockIdx.x / BH;  // heaviest (latest) query tiles first
-  const int bh = (int)blockIdx.x % BH, b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
+  int rank, bh;
+  tile_order((int)blockIdx.x, (int)gridDim.x, nqt, BH, p.group, rank, bh);
+  const int qt = nqt - 1 - rank;  // heaviest (latest) query tiles first
+  const int b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
   const int q0 = qt * 128, off = p.Tk - p.Tq;
   const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
   const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
@@ -197,8 +219,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int BH = p.B * p.nh;
   const int nqt = (p.Tq + 127) / 128;
-  const int qt = nqt - 1 - (int)blockIdx.x / BH;
-  const int bh = (int)blockIdx.x % BH, b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
+  int rank, bh;
+  tile_order((int)blockIdx.x, (int)gridDim.x, nqt, BH, p.group, rank, bh);
+  const int qt = nqt - 1 - rank;
+  const int b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
   const int q0 = qt * 128, off = p.Tk - p.Tq;
   const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
   const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + h * HS;
@@ -316,8 +340,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int BHk = p.B * p.nkv;
-  const int kt = (int)blockIdx.x / BHk;  // low key tiles (most queries) first
-  const int bh = (int)blockIdx.x % BHk, b = bh / p.nkv, kvh = bh % p.nkv;
+  int kt, bh;
+  tile_order((int)blockIdx.x, (int)gridDim.x, (p.Tk + 127) / 128, BHk, p.group, kt, bh);  // low key tiles (most queries) first
+  const int b = bh / p.nkv, kvh = bh % p.nkv;
   const int G = p.nh / p.nkv;
   const int k0 = kt * 128, off = p.Tk - p.Tq;
   const int kw0 = k0 + wave * 32;
@@ -467,14 +492,27 @@ static void bwd_launch(const AttnParams& p, hipStream_t st) {
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
 }
 
-void attn_fwd(const AttnParams& p, hipStream_t st) {
-  if (p.B == 0 || p.Tq == 0) return;
+// Heads per XCD-local group. Measured on MI355X (benchmarks/attn_bench.py): groups of 4 heads gain
+// 3-5 % in the backward kernels and up to 9 % with grouped-query heads at T <= 2048; with more
+// than 16 tiles per head the longer tail of a group outweighs the L2 reuse. DPA_ATTN_GROUP overrides.
+static int tile_group(int tiles_per_head) {
+  static const int g = [] { const char* e = getenv("DPA_ATTN_GROUP"); return e ? atoi(e) : -1; }();
+  if (g >= 0) return g;
+  return tiles_per_head <= 16 ? 4 : 0;
+}
+
+void attn_fwd(const AttnParams& p0, hipStream_t st) {
+  if (p0.B == 0 || p0.Tq == 0) return;
+  AttnParams p = p0;
+  p.group = tile_group((p.Tq + 127) / 128);
   if (p.hs == 64) fwd_launch<64>(p, st);
   else fwd_launch<128>(p, st);
 }
 
-void attn_bwd(const AttnParams& p, hipStream_t st) {
-  if (p.B == 0 || p.Tq == 0) return;
+void attn_bwd(const AttnParams& p0, hipStream_t st) {
+  if (p0.B == 0 || p0.Tq == 0) return;
+  AttnParams p = p0;
+  p.group = tile_group((p.Tq + 127) / 128);
   if (p.hs == 64) bwd_launch<64>(p, st);
   else bwd_launch<128>(p, st);
 }

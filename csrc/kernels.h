@@ -62,6 +62,7 @@ struct AttnParams {
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
   int q_ts, k_ts, v_ts, o_ts, do_ts, dq_ts, dk_ts, dv_ts;
   float scale;
+  int group;           // tile order: 0 = tile-major over all heads; G > 0 = XCD-local groups of G heads
 };
 void attn_fwd(const AttnParams& p, hipStream_t st);
 void attn_bwd(const AttnParams& p, hipStream_t st);
