@@ -16,6 +16,8 @@
 //  * Backward is split in two kernels so no cross-workgroup reduction (atomics) is needed:
 //    one workgroup owns 128 keys and sweeps the queries (dK, dV), the other owns 128 queries
 //    and sweeps the keys (dQ). P is recomputed from the saved log-sum-exp.
+//  * Attention dropout (template flag, off in the default instantiation) is applied to the
+//    probability registers from a stateless per-pair hash, so no mask is stored or exchanged.
 //  * The causal mask is bottom-right aligned (query i sees keys <= i + Tk - Tq), which is what
 //    KV-cache decoding needs. Heaviest tiles are launched first.
 //
@@ -59,6 +61,30 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDefer = 6.0f;   // deferred-rescale threshold of the forward, in log2 units
 
+// Dropout mask: keep(q, k) for one (batch, head) is a 32-bit mix of the pair's index with a per-head
+// key derived from the 64-bit seed. Stateless, so the forward and both backward kernels (which visit
+// the pairs in different orders and layouts) regenerate the same mask; about ten integer operations
+// per score.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned drop_key(const long long* seed, int bh) {
+  const unsigned long long s = (unsigned long long)*seed;
+  return mix32((unsigned)s ^ ((unsigned)bh * 0x27D4EB2Fu)) ^ (unsigned)(s >> 32);
+}
+__device__ __forceinline__ unsigned drop_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+__device__ __forceinline__ bool drop_keep(unsigned key, int q, int k, unsigned thresh) {
+  return mix32(((unsigned)q * 0x9E3779B1u + (unsigned)k) ^ key) >= thresh;
+}
+
 // Which (tile rank, batch*head) a workgroup works on. rank 0 is the heaviest tile of its head.
 // group == 0: rank-major over all heads (all heaviest tiles first). group == G: workgroups are
 // re-labelled so that each XCD (own L2) owns a contiguous run of heads, and inside it the tiles of G
@@ -81,7 +107,7 @@ __device__ __forceinline__ void tile_order(int bid, int nwg, int ntile, int BH, 
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
-template <int HS>
+template <int HS, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,6 +151,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const float c = p.scale * kLog2e;
   int qlim = qrow + off;
   if (qlim > p.Tk - 1) qlim = p.Tk - 1;
+  const unsigned dkey = DROP ? drop_key(p.seed, bh) : 0u, dthr = DROP ? drop_threshold(p.p_drop) : 0u;
 
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) {
@@ -181,8 +208,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][i], c, -mc));
-          s[sub][i] = pv;
-          rs += pv;
+          rs += pv;   // the softmax normaliser is that of the undropped row
+          s[sub][i] = (DROP && !drop_keep(dkey, qrow, kv0 + sub * 32 + acc_row(i, hh), dthr)) ? 0.f : pv;
         }
       l += rs;
 #pragma unroll
@@ -202,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.f / l;
+  const float inv = (DROP ? 1.f / (1.f - p.p_drop) : 1.f) / l;
   if (hh == 0 && qrow < p.Tq) p.lse[((long long)b * p.nh + h) * p.Tq + qrow] = m * p.scale + __logf(l);
   __syncthreads();  // all waves are done with the K/V tiles before the region is reused
   bf16_t* op = (bf16_t*)p.o + b * p.o_bs + h * HS;
@@ -212,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------
 // Backward, dQ: one workgroup = 128 queries, sweeps the keys. Also writes delta[b, h, q] = sum_d dO * O.
 // ------------------------------------------------------------------------------------------
-template <int HS>
+template <int HS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -274,6 +301,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const float c = p.scale * kLog2e;
   int qlim = qrow + off;
   if (qlim > p.Tk - 1) qlim = p.Tk - 1;
+  const unsigned dkey = DROP ? drop_key(p.seed, bh) : 0u, dthr = DROP ? drop_threshold(p.p_drop) : 0u;
+  const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
 
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) {
@@ -305,7 +334,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
           for (int i = 0; i < 16; ++i) {
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -lse2));
             if (MASK && (kv0 + sub * 32 + acc_row(i, hh) > qlim)) pv = 0.f;
-            s[i] = pv * (dp[i] - dlt);  // dS^T
+            float dpi = dp[i];
+            if (DROP) dpi = drop_keep(dkey, qrow, kv0 + sub * 32 + acc_row(i, hh), dthr) ? dpi * rkeep : 0.f;
+            s[i] = pv * (dpi - dlt);  // dS^T
           }
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
@@ -334,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // Backward, dK/dV: one workgroup = 128 keys of one (batch, kv head); each wave keeps dK^T and
 // dV^T of its 32 keys in registers and sweeps the query heads of the group x the query tiles.
 // ------------------------------------------------------------------------------------------
-template <int HS>
+template <int HS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2, BUF = 2 * TILE + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -375,6 +406,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       dvacc[dt][i] = 0.f;
     }
   const float c = p.scale * kLog2e;
+  const unsigned dthr = DROP ? drop_threshold(p.p_drop) : 0u;
+  const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
 
   Stage64<HS> qs_, ds_;
   float stat = 0.f;  // threads 0..63: lse*log2e of query tid; threads 64..127: delta of query tid-64
@@ -409,6 +442,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const char* dob = qb + TILE;
     const char* stb = qb + 2 * TILE;
     const int qt0 = q_start + (it % nqt) * 64;
+    const unsigned dkey = DROP ? drop_key(p.seed, b * p.nh + kvh * G + it / nqt) : 0u;
     auto block = [&](int sub, auto mask_tag) {
       constexpr bool MASK = decltype(mask_tag)::value;
       f32x16 s, dp;
@@ -431,8 +465,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
           const int i = 4 * g4 + j;
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[j]));
           if (MASK && (key > qt0 + rr + j + off)) pv = 0.f;
-          s[i] = pv;                    // P
-          dp[i] = pv * (dp[i] - d4[j]);  // dS
+          float pd = pv, dpi = dp[i];
+          if (DROP) {
+            const bool keep = drop_keep(dkey, qt0 + rr + j, key, dthr);
+            pd = keep ? pv * rkeep : 0.f;
+            dpi = keep ? dpi * rkeep : 0.f;
+          }
+          s[i] = pd;                    // P (dropped and rescaled: the weights dV sees)
+          dp[i] = pv * (dpi - d4[j]);   // dS
         }
       }
 #pragma unroll
@@ -468,28 +508,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
-template <int HS>
+template <int HS, bool DROP>
 static void fwd_launch(const AttnParams& p, hipStream_t st) {
   const int nqt = (p.Tq + 127) / 128;
   const size_t lds = 4 * 64 * HS * 2;
-  hipLaunchKernelGGL((attn_fwd_kernel<HS>), dim3(nqt * p.B * p.nh), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<HS, DROP>), dim3(nqt * p.B * p.nh), dim3(256), lds, st, p);
 }
 
-template <int HS>
+template <int HS, bool DROP>
 static void bwd_launch(const AttnParams& p, hipStream_t st) {
   // dQ first: it also produces delta, which the dK/dV kernel consumes.
   const int nqt = (p.Tq + 127) / 128;
   const size_t lds_q = 4 * 64 * HS * 2;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HS>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HS, DROP>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
   const int nkt = (p.Tk + 127) / 128;
   const size_t lds_kv = 2 * (2 * 64 * HS * 2 + 512);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_kv);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS, DROP>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
+}
+
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(unsigned char* __restrict__ keep, int nh, int Tq,
+                                                                int Tk, float p_drop,
+                                                                const long long* __restrict__ seed, long long total) {
+  const unsigned thr = drop_threshold(p_drop);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Tk);
+    const long long rest = i / Tk;
+    const int q = (int)(rest % Tq), bh = (int)(rest / Tq);
+    keep[i] = drop_keep(drop_key(seed, bh), q, k, thr) ? 1 : 0;
+  }
+}
+
+void attn_dropout_mask(unsigned char* keep, int B, int nh, int Tq, int Tk, float p_drop, const long long* seed,
+                       hipStream_t st) {
+  const long long total = (long long)B * nh * Tq * Tk;
+  if (total == 0) return;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, keep, nh, Tq, Tk, p_drop, seed,
+                     total);
 }
 
 // Heads per XCD-local group. Measured on MI355X (benchmarks/attn_bench.py): groups of 4 heads gain
@@ -505,16 +568,18 @@ void attn_fwd(const AttnParams& p0, hipStream_t st) {
   if (p0.B == 0 || p0.Tq == 0) return;
   AttnParams p = p0;
   p.group = tile_group((p.Tq + 127) / 128);
-  if (p.hs == 64) fwd_launch<64>(p, st);
-  else fwd_launch<128>(p, st);
+  const bool drop = p.p_drop > 0.f && p.seed != nullptr;
+  if (p.hs == 64) drop ? fwd_launch<64, true>(p, st) : fwd_launch<64, false>(p, st);
+  else drop ? fwd_launch<128, true>(p, st) : fwd_launch<128, false>(p, st);
 }
 
 void attn_bwd(const AttnParams& p0, hipStream_t st) {
   if (p0.B == 0 || p0.Tq == 0) return;
   AttnParams p = p0;
   p.group = tile_group((p.Tq + 127) / 128);
-  if (p.hs == 64) bwd_launch<64>(p, st);
-  else bwd_launch<128>(p, st);
+  const bool drop = p.p_drop > 0.f && p.seed != nullptr;
+  if (p.hs == 64) drop ? bwd_launch<64, true>(p, st) : bwd_launch<64, false>(p, st);
+  else drop ? bwd_launch<128, true>(p, st) : bwd_launch<128, false>(p, st);
 }
 
 }  // namespace dpa

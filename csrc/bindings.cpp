@@ -344,8 +344,31 @@ dpa::AttnParams attn_params(const Tensor& q, const Tensor& k, const Tensor& v, d
   return p;
 }
 
-std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale) {
+// Dropout: p_drop in [0, 1) and, when positive, a one-element int64 device tensor holding the seed.
+void set_dropout(dpa::AttnParams& p, double p_drop, const std::optional<Tensor>& seed) {
+  TORCH_CHECK(p_drop >= 0.0 && p_drop < 1.0, "attention: dropout probability must be in [0, 1)");
+  p.p_drop = (float)p_drop;
+  p.seed = nullptr;
+  if (p_drop > 0.0) {
+    TORCH_CHECK(seed.has_value() && seed->is_cuda() && seed->scalar_type() == at::kLong && seed->numel() == 1,
+                "attention: dropout needs a one-element int64 seed tensor on the GPU");
+    p.seed = (const long long*)seed->data_ptr<int64_t>();
+  }
+}
+
+Tensor attn_dropout_mask(int64_t B, int64_t nh, int64_t Tq, int64_t Tk, double p_drop, const Tensor& seed) {
+  TORCH_CHECK(seed.is_cuda() && seed.scalar_type() == at::kLong && seed.numel() == 1, "seed: int64 [1] on the GPU");
+  TORCH_CHECK(p_drop >= 0.0 && p_drop < 1.0 && B >= 0 && nh >= 0 && Tq >= 0 && Tk > 0, "attn_dropout_mask: bad arguments");
+  Tensor keep = at::empty({B, nh, Tq, Tk}, seed.options().dtype(at::kByte));
+  dpa::attn_dropout_mask(keep.data_ptr<uint8_t>(), (int)B, (int)nh, (int)Tq, (int)Tk, (float)p_drop,
+                         (const long long*)seed.data_ptr<int64_t>(), cur_stream());
+  return keep.to(at::kBool);
+}
+
+std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, double p_drop,
+                                    const std::optional<Tensor>& seed) {
   dpa::AttnParams p = attn_params(q, k, v, scale);
+  set_dropout(p, p_drop, seed);
   Tensor o = at::empty({q.size(0), q.size(1), q.size(2), q.size(3)}, q.options());
   Tensor lse = at::empty({q.size(0), q.size(2), q.size(1)}, q.options().dtype(at::kFloat));
   p.o = o.data_ptr();
@@ -357,8 +380,10 @@ std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tens
 }
 
 void attn_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
-              const Tensor& lse, Tensor dq, Tensor dk, Tensor dv, double scale) {
+              const Tensor& lse, Tensor dq, Tensor dk, Tensor dv, double scale, double p_drop,
+              const std::optional<Tensor>& seed) {
   dpa::AttnParams p = attn_params(q, k, v, scale);
+  set_dropout(p, p_drop, seed);
   const int64_t hs = q.size(3);
   check_heads(dout, "dout", hs);
   check_heads(o, "o", hs);
@@ -736,9 +761,10 @@ TORCH_LIBRARY(dpa, m) {
   m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
   m.def("swiglu_fwd(Tensor h) -> Tensor");
   m.def("swiglu_bwd(Tensor dy, Tensor h) -> Tensor");
-  m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale) -> (Tensor, Tensor)");
+  m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, float p_drop=0.0, Tensor? seed=None) -> (Tensor, Tensor)");
+  m.def("attn_dropout_mask(int B, int nh, int Tq, int Tk, float p_drop, Tensor seed) -> Tensor");
   m.def("attn_bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor(a!) dq, Tensor(b!) dk, "
-        "Tensor(c!) dv, float scale) -> ()");
+        "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None) -> ()");
   m.def("rope_(Tensor(a!) x, Tensor cos_t, Tensor sin_t, int pos0, bool inverse) -> ()");
 }
 
@@ -779,6 +805,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("swiglu_fwd", swiglu_fwd);
   m.impl("swiglu_bwd", swiglu_bwd);
   m.impl("attn_fwd", attn_fwd);
+  m.impl("attn_dropout_mask", attn_dropout_mask);
   m.impl("attn_bwd", attn_bwd);
   m.impl("rope_", rope_);
 }

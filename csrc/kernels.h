@@ -63,9 +63,16 @@ struct AttnParams {
   int q_ts, k_ts, v_ts, o_ts, do_ts, dq_ts, dk_ts, dv_ts;
   float scale;
   int group;           // tile order: 0 = tile-major over all heads; G > 0 = XCD-local groups of G heads
+  // Attention dropout (p_drop > 0): the keep mask is a counter-based hash of (seed, batch*head, query,
+  // key), evaluated in registers by all three kernels; the seed is read from device memory.
+  float p_drop;
+  const long long* seed;
 };
 void attn_fwd(const AttnParams& p, hipStream_t st);
 void attn_bwd(const AttnParams& p, hipStream_t st);
+// keep[b, h, q, k] (1 byte each) of the dropout mask the attention kernels apply for this seed.
+void attn_dropout_mask(unsigned char* keep, int B, int nh, int Tq, int Tk, float p_drop, const long long* seed,
+                       hipStream_t st);
 
 // ---- Weight-gradient GEMM -----------------------------------------------------------------
 // ws[N, K] (fp32) += dy[M, N]^T * x[M, K]; dbias[N] (fp32, optional) += column sums of dy.

@@ -5,8 +5,11 @@
 ``o [B, Tq, nh, hs]``. Query ``i`` attends to keys ``<= i + Tk - Tq``; with ``Tq == Tk`` this is
 the usual causal mask and with a KV cache (``Tq < Tk``) the new tokens see the whole cache.
 
-GPU path: the hand-written flash kernels (bf16, hs in {64, 128}).
-Eager path (CPU, fp32 checks, other head sizes): explicit-mask SDPA.
+GPU path: the hand-written flash kernels (bf16, hs in {64, 128}; other widths up to 128 zero-padded).
+Attention dropout runs inside them: the keep mask is a stateless hash of (seed, head, query, key)
+that the forward and both backward kernels regenerate, the seed is one device integer drawn from
+torch's GPU generator (so ``manual_seed``, activation recomputation and hipGraph replay treat it like
+any other random op). Eager path (CPU, fp32 checks): explicit-mask SDPA.
 
 Reference behaviour: ``F.scaled_dot_product_attention(q, k, v, is_causal=True)`` after
 ``repeat_interleave`` of the KV heads (reference: single-gpu/model.py:144-149). The reference's
@@ -44,18 +47,33 @@ def _packed(t: torch.Tensor) -> torch.Tensor:
     return t if ok else t.contiguous()
 
 
+def _draw_seed(dropout_p: float, device) -> torch.Tensor | None:
+    """One int64 on the device from torch's generator of that device (no host round trip)."""
+    if dropout_p <= 0.0:
+        return None
+    return torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=device)
+
+
+def dropout_keep_mask(B: int, nh: int, Tq: int, Tk: int, dropout_p: float, seed: torch.Tensor) -> torch.Tensor:
+    """The boolean keep mask ``[B, nh, Tq, Tk]`` the kernels apply for ``seed`` (tests, debugging)."""
+    return ops().attn_dropout_mask(B, nh, Tq, Tk, float(dropout_p), seed)
+
+
 class _FlashAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, scale):
+    def forward(ctx, q, k, v, scale, dropout_p=0.0, seed=None):
         q, k, v = _packed(q), _packed(k), _packed(v)
-        o, lse = ops().attn_fwd(q, k, v, scale)
-        ctx.save_for_backward(q, k, v, o, lse)
+        if seed is None:
+            seed = _draw_seed(dropout_p, q.device)
+        o, lse = ops().attn_fwd(q, k, v, scale, dropout_p, seed)
+        ctx.save_for_backward(q, k, v, o, lse, seed)
         ctx.scale = scale
+        ctx.dropout_p = dropout_p
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, lse, seed = ctx.saved_tensors
         B, Tq, nh, hs = q.shape
         Tk, nkv = k.shape[1], k.shape[2]
         do = _packed(do)
@@ -68,8 +86,8 @@ class _FlashAttnFn(torch.autograd.Function):
             dv = dqkv[..., (nh + nkv) * hs:].view(B, Tk, nkv, hs)
         else:
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        ops().attn_bwd(do, q, k, v, o, lse, dq, dk, dv, ctx.scale)
-        return dq, dk, dv, None
+        ops().attn_bwd(do, q, k, v, o, lse, dq, dk, dv, ctx.scale, ctx.dropout_p, seed)
+        return dq, dk, dv, None, None, None
 
 
 def split_qkv(qkv: torch.Tensor, nh: int, nkv: int):
@@ -87,23 +105,24 @@ class _FlashAttnQKVFn(torch.autograd.Function):
     one fused buffer that is returned as the gradient of ``qkv`` (no split/cat copies)."""
 
     @staticmethod
-    def forward(ctx, qkv, nh, nkv, scale):
+    def forward(ctx, qkv, nh, nkv, scale, dropout_p=0.0):
         qkv = qkv if (qkv.is_contiguous() and qkv.data_ptr() % 16 == 0) else qkv.contiguous()
         q, k, v = split_qkv(qkv, nh, nkv)
-        o, lse = ops().attn_fwd(q, k, v, scale)
-        ctx.save_for_backward(qkv, o, lse)
-        ctx.cfg = (nh, nkv, scale)
+        seed = _draw_seed(dropout_p, qkv.device)
+        o, lse = ops().attn_fwd(q, k, v, scale, dropout_p, seed)
+        ctx.save_for_backward(qkv, o, lse, seed)
+        ctx.cfg = (nh, nkv, scale, dropout_p)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse = ctx.saved_tensors
-        nh, nkv, scale = ctx.cfg
+        qkv, o, lse, seed = ctx.saved_tensors
+        nh, nkv, scale, dropout_p = ctx.cfg
         q, k, v = split_qkv(qkv, nh, nkv)
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = split_qkv(dqkv, nh, nkv)
-        ops().attn_bwd(_packed(do), q, k, v, o, lse, dq, dk, dv, scale)
-        return dqkv, None, None, None
+        ops().attn_bwd(_packed(do), q, k, v, o, lse, dq, dk, dv, scale, dropout_p, seed)
+        return dqkv, None, None, None, None
 
 
 def causal_self_attention_qkv(qkv: torch.Tensor, nh: int, nkv: int, scale: float | None = None,
@@ -112,8 +131,8 @@ def causal_self_attention_qkv(qkv: torch.Tensor, nh: int, nkv: int, scale: float
     hs = qkv.shape[-1] // (nh + 2 * nkv)
     if scale is None:
         scale = 1.0 / math.sqrt(hs)
-    if dropout_p == 0.0 and use_hip(qkv) and qkv.dtype == torch.bfloat16 and hs in (64, 128):
-        return _FlashAttnQKVFn.apply(qkv, nh, nkv, float(scale))
+    if use_hip(qkv) and qkv.dtype == torch.bfloat16 and hs in (64, 128):
+        return _FlashAttnQKVFn.apply(qkv, nh, nkv, float(scale), float(dropout_p))
     q, k, v = split_qkv(qkv, nh, nkv)
     return causal_attention_eager(q, k, v, float(scale), dropout_p)
 
@@ -134,17 +153,19 @@ def causal_attention_eager(q, k, v, scale: float, dropout_p: float = 0.0) -> tor
 
 
 def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float | None = None,
-                     dropout_p: float = 0.0) -> torch.Tensor:
+                     dropout_p: float = 0.0, seed: torch.Tensor | None = None) -> torch.Tensor:
+    """``seed`` (int64 ``[1]`` on the GPU) pins the dropout mask; by default one is drawn per call."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
-    if dropout_p == 0.0 and _hip_ok(q, k, v):
-        return _FlashAttnFn.apply(q, k, v, float(scale))
-    if dropout_p == 0.0 and _paddable(q, k, v):
+    dropout_p = float(dropout_p)
+    if _hip_ok(q, k, v):
+        return _FlashAttnFn.apply(q, k, v, float(scale), dropout_p, seed)
+    if _paddable(q, k, v):
         # Other head sizes up to 128 run on the flash kernels too: zero features change neither the
         # scores (the scale is explicit) nor the kept output columns, and no T x T matrix is formed.
         hs, dv = q.shape[-1], v.shape[-1]
         tgt = 64 if max(hs, dv) <= 64 else 128
         qp, kp = F.pad(q, (0, tgt - hs)), F.pad(k, (0, tgt - hs))
         vp = F.pad(v, (0, tgt - dv))
-        return _FlashAttnFn.apply(qp, kp, vp, float(scale))[..., :dv]
+        return _FlashAttnFn.apply(qp, kp, vp, float(scale), dropout_p, seed)[..., :dv]
     return causal_attention_eager(q, k, v, float(scale), dropout_p)

@@ -586,3 +586,59 @@ def test_out_of_range_ids_and_targets_are_contained():
     loss = ops.cross_entropy(logits, tgt)
     loss.backward()
     assert torch.isfinite(loss) and torch.isfinite(logits.grad).all()
+
+
+def _masked_attention_reference(q, k, v, scale, keep, p):
+    """fp32 attention with an explicit dropout keep mask [B, nh, Tq, Tk] applied to the probabilities."""
+    B, Tq, nh, hs = q.shape
+    Tk, nkv = k.shape[1], k.shape[2]
+    qh, kh, vh = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+    kh = kh.repeat_interleave(nh // nkv, dim=1)
+    vh = vh.repeat_interleave(nh // nkv, dim=1)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    causal = torch.ones(Tq, Tk, dtype=torch.bool, device=q.device).tril(diagonal=Tk - Tq)
+    s = s.masked_fill(~causal, float("-inf"))
+    pr = torch.softmax(s, dim=-1) * keep.to(s.dtype) / (1.0 - p)
+    return (pr @ vh).transpose(1, 2)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,nh,nkv,hs,p", [(2, 256, 256, 4, 4, 64, 0.1), (1, 200, 200, 8, 2, 64, 0.25),
+                                                  (2, 128, 128, 4, 2, 128, 0.1), (1, 70, 198, 4, 4, 64, 0.5)])
+def test_flash_attention_dropout_matches_masked_reference(B, Tq, Tk, nh, nkv, hs, p):
+    """In-kernel dropout: the forward and both backward kernels regenerate one mask from the seed; the
+    mask kernel exposes it, and fp32 attention with that explicit mask is the oracle."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    q = torch.randn(B, Tq, nh, hs, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(B, Tk, nkv, hs, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(B, Tk, nkv, hs, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    do = torch.randn(B, Tq, nh, hs, device=DEV, dtype=torch.bfloat16)
+    seed = torch.tensor([1234567890123], dtype=torch.int64, device=DEV)
+    scale = 1.0 / math.sqrt(hs)
+    o = ops.causal_attention(q, k, v, scale, dropout_p=p, seed=seed)
+    o.backward(do)
+    keep = ops.dropout_keep_mask(B, nh, Tq, Tk, p, seed)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1.0 - p)) < 0.01, frac
+    # different heads and different seeds give different masks
+    assert not torch.equal(keep[0, 0], keep[0, 1])
+    assert not torch.equal(keep, ops.dropout_keep_mask(B, nh, Tq, Tk, p, seed + 1))
+    qr, kr, vr = [t.detach().float().requires_grad_() for t in (q, k, v)]
+    ref = _masked_attention_reference(qr, kr, vr, scale, keep, p)
+    ref.backward(do.float())
+    assert rel_err(o, ref) < 1e-2
+    assert rel_err(q.grad, qr.grad) < 2e-2 and rel_err(k.grad, kr.grad) < 2e-2 and rel_err(v.grad, vr.grad) < 2e-2
+
+
+def test_attention_dropout_draws_a_new_mask_per_call_and_respects_manual_seed():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    qkv = torch.randn(2, 128, 3 * 4 * 64, device=DEV, dtype=torch.bfloat16)
+    torch.manual_seed(7)
+    a = ops.causal_self_attention_qkv(qkv, 4, 4, dropout_p=0.2)
+    b = ops.causal_self_attention_qkv(qkv, 4, 4, dropout_p=0.2)
+    torch.manual_seed(7)
+    a2 = ops.causal_self_attention_qkv(qkv, 4, 4, dropout_p=0.2)
+    assert not torch.equal(a, b) and torch.equal(a, a2)
+    assert torch.equal(ops.causal_self_attention_qkv(qkv, 4, 4, dropout_p=0.0),
+                       ops.causal_self_attention_qkv(qkv, 4, 4))
