@@ -140,6 +140,22 @@ def test_graphed_step_matches_eager_steps():
     assert ((w1 - w2).norm() / w1.norm()).item() < 2e-2
 
 
+def test_graphed_step_with_dropout_captures_and_redraws_masks():
+    """dropout > 0 under hipGraph replay: the seed draw is a generator op the capture registers, so
+    the step is captured (no eager fallback) and replays of the SAME batch give different losses."""
+    from distributed_pytorch_amd.parallel.engine import Engine
+    from distributed_pytorch_amd.parallel.graph import GraphedTrainStep
+    cfg = LLMconfig(**{**BASE, **VARIANTS["gpt2"], "dropout": 0.2}).finalize()
+    torch.manual_seed(2)
+    eng = Engine(LLM(cfg), dtype="bf16", device="cuda:0", lr=0.0)
+    eng.train()
+    gs = GraphedTrainStep(eng, accum=1, grad_clip=1.0, warmup=1)
+    x = torch.randint(0, cfg.vocab_size, (4, 256), device="cuda")
+    losses = [gs.step([(x, x.roll(-1, 1))], 0.0).item() for _ in range(5)]
+    assert gs.graph is not None and not gs.failed
+    assert len({round(v, 6) for v in losses[2:]}) > 1, losses   # lr = 0: only the masks change
+
+
 def test_trainer_resume_on_gpu(tmp_path):
     """Save a resume file mid-run on the GPU, continue from it in a new trainer call (loader RNG state
     comes back from a file mapped to the GPU) and land on the same loss as the uninterrupted run."""
