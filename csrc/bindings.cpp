@@ -285,6 +285,23 @@ Tensor gelu_bwd(const Tensor& dy, const Tensor& x) {
   dpa::gelu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), is_bf16(x), cur_stream());
   return dx;
 }
+Tensor act_fwd(const Tensor& x, int64_t kind) {
+  check_act(x, "x");
+  TORCH_CHECK(x.numel() % 8 == 0 && kind >= 0 && kind < dpa::act_kinds(), "act_fwd: bad size or kind");
+  Tensor y = at::empty_like(x);
+  dpa::act_apply((int)kind, nullptr, x.data_ptr(), y.data_ptr(), x.numel(), is_bf16(x), cur_stream());
+  return y;
+}
+Tensor act_bwd(const Tensor& dy, const Tensor& x, int64_t kind) {
+  check_act(x, "x");
+  check_act(dy, "dy");
+  TORCH_CHECK(x.numel() % 8 == 0 && dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type() && kind >= 0 &&
+                  kind < dpa::act_kinds(),
+              "act_bwd: bad size or kind");
+  Tensor dx = at::empty_like(x);
+  dpa::act_apply((int)kind, dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), is_bf16(x), cur_stream());
+  return dx;
+}
 Tensor swiglu_fwd(const Tensor& h) {
   check_act(h, "h");
   const int64_t U = h.size(-1) / 2;
@@ -759,6 +776,8 @@ TORCH_LIBRARY(dpa, m) {
   m.def("pos_bwd(Tensor dout, Tensor(a!) dpos, int pos0) -> ()");
   m.def("gelu_fwd(Tensor x) -> Tensor");
   m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
+  m.def("act_fwd(Tensor x, int kind) -> Tensor");
+  m.def("act_bwd(Tensor dy, Tensor x, int kind) -> Tensor");
   m.def("swiglu_fwd(Tensor h) -> Tensor");
   m.def("swiglu_bwd(Tensor dy, Tensor h) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, float p_drop=0.0, Tensor? seed=None) -> (Tensor, Tensor)");
@@ -802,6 +821,8 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("pos_bwd", pos_bwd);
   m.impl("gelu_fwd", gelu_fwd);
   m.impl("gelu_bwd", gelu_bwd);
+  m.impl("act_fwd", act_fwd);
+  m.impl("act_bwd", act_bwd);
   m.impl("swiglu_fwd", swiglu_fwd);
   m.impl("swiglu_bwd", swiglu_bwd);
   m.impl("attn_fwd", attn_fwd);

@@ -44,6 +44,10 @@ void pos_bwd(const void* dout, void* dpos, int B, int T_len, int pos0, int C, bo
 // ---- Activations -----------------------------------------------------------------------
 void gelu_fwd(const void* x, void* y, long long n, bool is_bf16, hipStream_t st);
 void gelu_bwd(const void* dy, const void* x, void* dx, long long n, bool is_bf16, hipStream_t st);
+// Other activations: kind 0..act_kinds()-1 = relu, silu, mish, selu, elu, sigmoid, tanh, leaky relu (0.01).
+// dy == nullptr: out = f(x); otherwise out = dy * f'(x).
+int act_kinds();
+void act_apply(int kind, const void* dy, const void* x, void* out, long long n, bool is_bf16, hipStream_t st);
 void swiglu_fwd(const void* h, void* y, long long M, int U, bool is_bf16, hipStream_t st);
 void swiglu_bwd(const void* dy, const void* h, void* dh, long long M, int U, bool is_bf16, hipStream_t st);
 

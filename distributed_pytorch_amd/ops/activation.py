@@ -1,6 +1,6 @@
-"""Feed-forward activations. GELU (exact erf) and SwiGLU have HIP forward/backward kernels;
-the remaining names of the reference's activation map run as stock elementwise ops
-(reference: single-gpu/model.py:376-394).
+"""Feed-forward activations. Every name of the reference's activation map has a HIP
+forward / backward kernel on the GPU (GELU exact-erf and SwiGLU their own, the rest one kernel
+templated on the function) and the stock op on the CPU (reference: single-gpu/model.py:376-394).
 """
 from __future__ import annotations
 
@@ -54,11 +54,42 @@ def swiglu(h: torch.Tensor) -> torch.Tensor:
     return F.silu(a) * b
 
 
-_ELEMENTWISE = {
-    "relu": F.relu, "gelu": gelu, "swish": F.silu, "silu": F.silu, "mish": F.mish, "selu": F.selu,
-    "celu": F.celu, "elu": F.elu, "sigmoid": torch.sigmoid, "tanh": torch.tanh,
-    "lrelu": lambda x: F.leaky_relu(x, 0.01),
+# kernel index (csrc/activation.hip::ActKind) and eager form of the other activations
+_KINDS = {
+    "relu": (0, F.relu), "silu": (1, F.silu), "swish": (1, F.silu), "mish": (2, F.mish), "selu": (3, F.selu),
+    "elu": (4, F.elu), "celu": (4, F.celu), "sigmoid": (5, torch.sigmoid), "tanh": (6, torch.tanh),
+    "lrelu": (7, lambda x: F.leaky_relu(x, 0.01)),
 }
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        ctx.kind = kind
+        return ops().act_fwd(xc, kind)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops().act_bwd(dy.contiguous(), x, ctx.kind), None
+
+
+def _elementwise(name: str):
+    kind, eager = _KINDS[name]
+
+    def fn(x: torch.Tensor) -> torch.Tensor:
+        if _hip_ok(x, 8):
+            return _ActFn.apply(x, kind)
+        return eager(x)
+
+    fn.__name__ = name
+    return fn
+
+
+_ELEMENTWISE = {name: _elementwise(name) for name in _KINDS}
+_ELEMENTWISE["gelu"] = gelu
 
 
 def get_activation(name: str):

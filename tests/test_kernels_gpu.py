@@ -642,3 +642,24 @@ def test_attention_dropout_draws_a_new_mask_per_call_and_respects_manual_seed():
     assert not torch.equal(a, b) and torch.equal(a, a2)
     assert torch.equal(ops.causal_self_attention_qkv(qkv, 4, 4, dropout_p=0.0),
                        ops.causal_self_attention_qkv(qkv, 4, 4))
+
+
+@pytest.mark.parametrize("name", ["relu", "silu", "swish", "mish", "selu", "elu", "celu", "sigmoid", "tanh", "lrelu"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_activation_map_kernels(name, dtype):
+    """Every activation name of the reference map runs on its HIP kernel and matches the stock op."""
+    import torch.nn.functional as F
+    from distributed_pytorch_amd.ops.activation import get_activation
+    eager = {"relu": F.relu, "silu": F.silu, "swish": F.silu, "mish": F.mish, "selu": F.selu, "elu": F.elu,
+             "celu": F.celu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "lrelu": lambda t: F.leaky_relu(t, 0.01)}[name]
+    torch.manual_seed(0)
+    x = (3 * torch.randn(64, 1024, device=DEV)).to(dtype).requires_grad_()
+    dy = torch.randn(64, 1024, device=DEV).to(dtype)
+    y = get_activation(name)(x)
+    assert y.grad_fn is not None and "ActFn" in type(y.grad_fn).__name__
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_()
+    yr = eager(xr)
+    yr.backward(dy.float())
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(y, yr) < tol and rel_err(x.grad, xr.grad) < tol
