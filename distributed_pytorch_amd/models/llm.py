@@ -354,8 +354,10 @@ class MoE(nn.Module):
         outs = []
         start = 0
         for i, c in enumerate(counts):
-            if c:
-                outs.append(self.experts[i + self.n_shared](xs[start:start + c]))
+            # an expert without tokens still runs (on an empty slice): its parameters stay in the
+            # autograd graph and receive zero gradients, so every rank's gradient hooks fire for the
+            # same parameters in the same order and the engines issue identical collective sequences
+            outs.append(self.experts[i + self.n_shared](xs[start:start + c]))
             start += c
         ys = torch.cat(outs, dim=0) * gs
         return torch.zeros_like(x_flat).index_add_(0, tok, ys.to(x_flat.dtype))

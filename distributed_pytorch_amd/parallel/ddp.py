@@ -35,6 +35,7 @@ class DDPEngine(Engine):
         self._pending = [0] * len(self.groups)
         self._launched = [False] * len(self.groups)
         self._works = []
+        self._next = len(self.groups) - 1
         self._in_backward_sync = False
         for gi, g in enumerate(self.groups):
             for s in g.slots:
@@ -44,14 +45,24 @@ class DDPEngine(Engine):
         def hook(param):
             self._pending[gi] -= 1
             if self._pending[gi] == 0 and self.require_backward_grad_sync and self._dist:
-                self._launch(gi)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Buckets are reduced strictly from the last to the first (the order in which the backward
+        pass completes them): a bucket goes out once it is complete AND every later bucket has gone.
+        The sequence of collectives is then the same on every rank even if some rank's hooks fire in
+        another order or not at all (such a bucket, and those before it, leave in finish_grad_sync)."""
+        while self._next >= 0 and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next -= 1
 
     def _pre_forward(self):
         for gi, g in enumerate(self.groups):
             self._pending[gi] = len(g.slots)
         if self.require_backward_grad_sync:
             self._launched = [False] * len(self.groups)
+            self._next = len(self.groups) - 1
 
     # -- collectives ------------------------------------------------------------------------
     def _launch(self, gi: int):
@@ -78,6 +89,7 @@ class DDPEngine(Engine):
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad()
         self._launched = [False] * len(self.groups)
+        self._next = len(self.groups) - 1
 
     def _grad_mul(self) -> float:
         return 1.0 / self.world

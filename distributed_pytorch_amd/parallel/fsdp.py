@@ -132,6 +132,7 @@ class FSDPEngine(Engine):
         self.block_units = self.units[1:]
         assert len(self.block_units) == len(blocks), "one FSDP unit per transformer block is expected"
         self._rs_inflight: deque = deque()
+        self._next_unit = len(self.units) - 1
         self._in_backward = False
         for i, (blk, u) in enumerate(zip(blocks, self.block_units)):
             blk.register_forward_pre_hook(self._make_pre_fwd(i))
@@ -177,7 +178,11 @@ class FSDPEngine(Engine):
             u = self.units[ui]
             u.pending -= 1
             if u.pending == 0 and self.require_backward_grad_sync:
-                self._reduce_unit(u)
+                # strictly last unit to first, the order backward completes them: every rank issues the
+                # same sequence of reduce-scatters whatever the order its hooks fire in
+                while self._next_unit >= 0 and self.units[self._next_unit].pending == 0:
+                    self._reduce_unit(self.units[self._next_unit])
+                    self._next_unit -= 1
         return hook
 
     def _reduce_unit(self, u: FSDPUnit):
@@ -198,6 +203,7 @@ class FSDPEngine(Engine):
         for u in self.units:
             u.pending = len(u.slots)
             u.reduced = False
+        self._next_unit = len(self.units) - 1
         self.root.wait_gather(self.group)
         if torch.is_grad_enabled():
             # gradients of the root unit (lm_head side) and of the final LayerNorm (last unit) are

@@ -160,3 +160,29 @@ def test_vocab_parallel_cross_entropy_matches_full():
     for loss, ref, gerr in run_distributed(_vp_worker, 2):
         assert abs(loss - ref) < 1e-5
         assert gerr < 1e-6
+
+
+def _launch_order_worker(rank, world):
+    """Record the order in which the DDP buckets are reduced and how many had left when backward ended."""
+    from distributed_pytorch_amd.parallel.ddp import DDPEngine
+    model, cfg = _make("gpt")
+    eng = DDPEngine(model, weight_decay=0.1, dtype="fp32", bucket_mb=0.05, eps=1e-5)
+    order = []
+    orig = eng._reduce_group
+    eng._reduce_group = lambda gi: (order.append(gi), orig(gi))[1]
+    x = torch.randint(0, cfg.vocab_size, (2, cfg.block_size))
+    eng.zero_grad()
+    _, loss, _ = eng(x, x)
+    loss.backward()
+    in_backward = len(order)
+    eng.step(1e-3)
+    return dict(order=order, in_backward=in_backward, ngroups=len(eng.groups))
+
+
+def test_ddp_buckets_leave_last_to_first_inside_backward():
+    """Overlap and determinism: every bucket is reduced from a gradient hook (during backward), in
+    strictly descending order on every rank."""
+    for out in run_distributed(_launch_order_worker, 2):
+        n = out["ngroups"]
+        assert n >= 3 and out["order"] == list(range(n - 1, -1, -1)), out
+        assert out["in_backward"] == n, out
