@@ -27,6 +27,18 @@ __device__ int pattern_addr(int pat, int lane, int k) {
     case 4: return r * 256 + 16 * ((2 * (k & 7) + hh) ^ (r & 15));                         // row read 128, xor (row & 15)
     case 5: return r * 128 + 16 * (2 * (k & 3) + hh) + (k >> 2) * 4096;                    // unswizzled rows of 128 B
     case 6: return r * 128 + 16 * ((2 * (k & 3) + hh) ^ ((r >> 1) & 7)) + (k >> 2) * 4096; // xor (row >> 1)
+    case 7: {   // Stage64<64>::commit: 8 lanes per 128-byte row, 8 rows per wave instruction
+      const int row = 8 * k + (lane >> 3);
+      return row * 128 + 16 * swz64(row, lane & 7);
+    }
+    case 8: {   // Stage64<128>::commit: 16 lanes per 256-byte row, 4 rows per wave instruction
+      const int row = 4 * k + (lane >> 4);
+      return row * 256 + 16 * swz128(row, lane & 15);
+    }
+    case 9: {   // the same 8-lanes-per-row layout written without the swizzle
+      const int row = 8 * k + (lane >> 3);
+      return row * 128 + 16 * (lane & 7);
+    }
     default: return 0;
   }
 }
@@ -87,10 +99,12 @@ int main() {
   hipMalloc(&ds, 4096);
   const int iters = 2000;
   const char* names0[] = {"linear", "row_frag<64> (swz64)", "rows128B xor(row&7)", "row_frag<128> (swz128)",
-                          "rows256B xor(row&15)", "rows128B unswizzled", "rows128B xor(row>>1)"};
+                          "rows256B xor(row&15)", "rows128B unswizzled", "rows128B xor(row>>1)",
+                          "Stage64<64> commit (8 lanes/row)", "Stage64<128> commit (16 lanes/row)",
+                          "8 lanes/row, no swizzle"};
   for (int waves = 1; waves <= 4; waves *= 4) {
     for (int mode = 0; mode < 3; ++mode) {
-      const int npat = mode == 1 ? 4 : 7;
+      const int npat = mode == 1 ? 4 : 10;
       for (int pat = 0; pat < npat; ++pat) {
         long long c = 0;
         for (int rep = 0; rep < 2; ++rep) {
