@@ -20,8 +20,10 @@ What is different underneath:
   the next LayerNorm;
 * MLA is expressed as multi-query flash attention over the latent KV (absorbed projections)
   instead of materialising ``(B, nh, T, T)`` scores;
-* MoE routes with one sort (no per-expert ``nonzero`` host round trips) and updates the
-  aux-free bias exactly once per training forward, also under activation recomputation;
+* MoE routes with a fused top-k gate kernel and runs the routed experts as grouped GEMMs over an
+  expert-sorted, block-padded token layout built on the device (no per-expert ``nonzero`` host
+  round trips, no expert loop); the aux-free bias is updated exactly once per training forward,
+  also under activation recomputation; attention dropout runs inside the flash kernels;
 * cached decoding uses a bottom-right aligned causal mask (the reference's GQA path attends to
   key 0 only when decoding from a cache).
 """
@@ -329,9 +331,11 @@ class MoE(nn.Module):
         return topk_indices, topk_gates.to(x_flat.dtype), aux_loss
 
     def routed_experts_local(self, x_flat, topk_indices, topk_gates):
-        """Sort the (token, slot) pairs by expert once, run every expert on its contiguous slice,
-        scale by the gate and scatter-add back. One host read of the per-expert counts replaces
-        the reference's per-expert ``nonzero``."""
+        """Routed experts on this rank. GPU path: grouped expert GEMMs over the padded expert-sorted
+        layout (no host sync). Fallback (CPU, dropout inside the experts, activations without a
+        grouped kernel): sort the (token, slot) pairs by expert once, run every expert on its
+        contiguous slice, scale by the gate and scatter-add back, with one host read of the
+        per-expert counts instead of the reference's per-expert ``nonzero``."""
         N, k = topk_indices.shape
         routed = self.experts[self.n_shared:]
         if not (self.training and self.config.dropout > 0):
