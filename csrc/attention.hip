@@ -118,7 +118,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   tile_order((int)blockIdx.x, (int)gridDim.x, nqt, BH, p.group, rank, bh);
   const int qt = nqt - 1 - rank;  // heaviest (latest) query tiles first
   const int b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
-  const int q0 = qt * 128, off = p.Tk - p.Tq;
+  int Tk = p.Tk;
+  if (p.kv_len != nullptr) {   // fill level of a preallocated cache (clamped to what is allocated)
+    const int n = *p.kv_len;
+    Tk = n < p.Tq ? p.Tq : (n > p.Tk ? p.Tk : n);
+  }
+  const int q0 = qt * 128, off = Tk - p.Tq;
   const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
   const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
   const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
@@ -132,13 +137,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 
   int kv_end = q0 + 128 + off;
-  if (kv_end > p.Tk) kv_end = p.Tk;
+  if (kv_end > Tk) kv_end = Tk;
   const int ntiles = (kv_end + 63) / 64;
   const int wave_qmax = q0 + wave * 32 + 31;
 
   Stage64<HS> ks_, vs_;
-  ks_.issue(kp, 0, p.Tk, p.k_ts, tid);
-  vs_.issue(vp, 0, p.Tk, p.v_ts, tid);
+  ks_.issue(kp, 0, Tk, p.k_ts, tid);
+  vs_.issue(vp, 0, Tk, p.v_ts, tid);
   ks_.commit(smem, tid);
   vs_.commit(smem + TILE, tid);
 
@@ -150,13 +155,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   float m = -INFINITY, l = 0.f;
   const float c = p.scale * kLog2e;
   int qlim = qrow + off;
-  if (qlim > p.Tk - 1) qlim = p.Tk - 1;
+  if (qlim > Tk - 1) qlim = Tk - 1;
   const unsigned dkey = DROP ? drop_key(p.seed, bh) : 0u, dthr = DROP ? drop_threshold(p.p_drop) : 0u;
 
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) {
-      ks_.issue(kp, (t + 1) * 64, p.Tk, p.k_ts, tid);
-      vs_.issue(vp, (t + 1) * 64, p.Tk, p.v_ts, tid);
+      ks_.issue(kp, (t + 1) * 64, Tk, p.k_ts, tid);
+      vs_.issue(vp, (t + 1) * 64, Tk, p.v_ts, tid);
     }
     __syncthreads();
     const char* kb = smem + (t & 1) * 2 * TILE;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) s[sub] = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s[sub]);
       }
-      const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > p.Tk);
+      const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > Tk);
       if (need_mask) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)

@@ -383,9 +383,14 @@ Tensor attn_dropout_mask(int64_t B, int64_t nh, int64_t Tq, int64_t Tk, double p
 }
 
 std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, double p_drop,
-                                    const std::optional<Tensor>& seed) {
+                                    const std::optional<Tensor>& seed, const std::optional<Tensor>& kv_len) {
   dpa::AttnParams p = attn_params(q, k, v, scale);
   set_dropout(p, p_drop, seed);
+  if (kv_len.has_value()) {
+    TORCH_CHECK(kv_len->is_cuda() && kv_len->scalar_type() == at::kInt && kv_len->numel() == 1,
+                "attention: kv_len must be a one-element int32 tensor on the GPU");
+    p.kv_len = kv_len->data_ptr<int>();
+  }
   Tensor o = at::empty({q.size(0), q.size(1), q.size(2), q.size(3)}, q.options());
   Tensor lse = at::empty({q.size(0), q.size(2), q.size(1)}, q.options().dtype(at::kFloat));
   p.o = o.data_ptr();
@@ -780,7 +785,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("act_bwd(Tensor dy, Tensor x, int kind) -> Tensor");
   m.def("swiglu_fwd(Tensor h) -> Tensor");
   m.def("swiglu_bwd(Tensor dy, Tensor h) -> Tensor");
-  m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, float p_drop=0.0, Tensor? seed=None) -> (Tensor, Tensor)");
+  m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? kv_len=None) -> (Tensor, Tensor)");
   m.def("attn_dropout_mask(int B, int nh, int Tq, int Tk, float p_drop, Tensor seed) -> Tensor");
   m.def("attn_bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor(a!) dq, Tensor(b!) dk, "
         "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None) -> ()");

@@ -71,6 +71,9 @@ struct AttnParams {
   // key), evaluated in registers by all three kernels; the seed is read from device memory.
   float p_drop;
   const long long* seed;
+  // Forward only: number of valid keys read from device memory (<= Tk, the allocated length). Lets a
+  // captured decode step run over a preallocated KV cache whose fill level changes between replays.
+  const int* kv_len;
 };
 void attn_fwd(const AttnParams& p, hipStream_t st);
 void attn_bwd(const AttnParams& p, hipStream_t st);

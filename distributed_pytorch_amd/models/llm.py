@@ -70,6 +70,45 @@ def _drop(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+class StaticKVCache:
+    """Preallocated key / value cache of the GQA family for decoding inside a captured hipGraph:
+    ``k[i], v[i] [B, S, nkv, hs]`` per layer, and the fill level as DEVICE scalars (``pos`` int64 =
+    position of the next token, ``len_after`` int32 = fill level once that token is appended), so
+    a replayed step needs no host-side shape or offset. ``advance()`` moves both by one."""
+
+    def __init__(self, config: LLMconfig, batch: int, max_len: int, device, dtype):
+        hs = config.n_embd // config.n_head
+        shape = (batch, max_len, config.n_kv_heads, hs)
+        self.k = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(config.n_layer)]
+        self.v = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(config.n_layer)]
+        self.max_len = max_len
+        self.pos = torch.zeros(1, dtype=torch.int64, device=device)
+        self.len_after = torch.ones(1, dtype=torch.int32, device=device)
+
+    def fill(self, caches, length: int):
+        """Load the prompt's keys / values (the dynamic caches ``(B, nkv, T, hs)`` of an eager forward)."""
+        for i, (ck, cv) in enumerate(caches):
+            self.k[i][:, :length].copy_(ck.transpose(1, 2))
+            self.v[i][:, :length].copy_(cv.transpose(1, 2))
+        self.pos.fill_(length)
+        self.len_after.fill_(length + 1)
+
+    def advance(self):
+        self.pos.add_(1)
+        self.len_after.add_(1)
+
+    def layer(self, i: int):
+        return _StaticLayer(self.k[i], self.v[i], self.pos, self.len_after)
+
+
+class _StaticLayer:
+    __slots__ = ("k", "v", "pos", "len_after")
+
+    def __init__(self, k, v, pos, len_after):
+        self.k, self.v, self.pos, self.len_after = k, v, pos, len_after
+
+
+# ---------------------------------------------------------------------------------------------
 class GQA(nn.Module):
     """Grouped-query attention (MHA / MQA / GQA) with or without RoPE
     (reference: single-gpu/model.py:98-155)."""
@@ -100,7 +139,14 @@ class GQA(nn.Module):
             cos_t, sin_t, pos0 = rope
             qk = ops.apply_rope(qkv[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, pos0)
             qkv = torch.cat([qk.view(B, T, (nh + nkv) * hs), qkv[..., (nh + nkv) * hs:]], dim=-1)
-        if kv_cache is None and not self._want_cache():
+        if isinstance(kv_cache, _StaticLayer):
+            # one new token appended in place at the device-side position, attention over the filled part
+            q, k, v = ops.split_qkv(qkv, nh, nkv)
+            kv_cache.k.index_copy_(1, kv_cache.pos, k)
+            kv_cache.v.index_copy_(1, kv_cache.pos, v)
+            y = ops.cached_attention(q, kv_cache.k, kv_cache.v, kv_cache.len_after)
+            new_cache = kv_cache
+        elif kv_cache is None and not self._want_cache():
             y = ops.causal_self_attention_qkv(qkv, nh, nkv, dropout_p=p_drop)
             new_cache = None
         else:
@@ -547,10 +593,22 @@ class LLM(nn.Module):
     def forward(self, idx: torch.Tensor, targets=None, kv_caches=None):
         cfg = self.config
         B, T = idx.shape
-        start_pos = self._start_pos(kv_caches)
         wte = self.lm_head.weight
-        x = ops.embedding(idx, wte, self._pos_table(wte.dtype, wte.device), start_pos)
-        rope = (self.rope_cos, self.rope_sin, start_pos) if cfg.pos_emb == "rope" else None
+        if isinstance(kv_caches, StaticKVCache):
+            # decode step over the preallocated cache: the position is a device scalar, so the position
+            # row / rotary rows are gathered on the device and handed to the kernels as 1-row tables
+            assert T == 1 and cfg.attn in ("mha", "mqa", "gqa"), "static cache: one token per step, GQA family"
+            static = kv_caches
+            ptab = self._pos_table(wte.dtype, wte.device)
+            x = ops.embedding(idx, wte, None if ptab is None else ptab.index_select(0, static.pos), 0)
+            rope = None
+            if cfg.pos_emb == "rope":
+                rope = (self.rope_cos.index_select(0, static.pos), self.rope_sin.index_select(0, static.pos), 0)
+            kv_caches = [static.layer(i) for i in range(cfg.n_layer)]
+        else:
+            start_pos = self._start_pos(kv_caches)
+            x = ops.embedding(idx, wte, self._pos_table(wte.dtype, wte.device), start_pos)
+            rope = (self.rope_cos, self.rope_sin, start_pos) if cfg.pos_emb == "rope" else None
         x = _drop(x, cfg.dropout, self.training)
         if kv_caches is None:
             kv_caches = [None] * cfg.n_layer
@@ -584,17 +642,91 @@ class LLM(nn.Module):
                 main_loss = ops.linear_cross_entropy(x, wte, targets, chunk_rows=self.loss_chunk_rows)
             loss = main_loss + total_aux / cfg.n_layer
         else:
-            logits = ops.linear(x[:, [-1], :], wte)
+            logits = ops.linear(x[:, -1:, :], wte)   # a slice, not a list index: no host-built index tensor
             loss = None
         return logits, loss, new_caches
 
     # ---- generation -----------------------------------------------------------------------
+    @staticmethod
+    def _sample(logits: torch.Tensor, temperature: float, topk: int | None) -> torch.Tensor:
+        """Next token ``[B, 1]`` from the last position's logits (temperature, top-k, multinomial);
+        no data-dependent host work, so it can be captured in a hipGraph."""
+        logits = logits[:, -1, :].float()
+        if temperature > 0:
+            logits = logits / temperature
+        if topk is not None:
+            v, _ = torch.topk(logits, min(topk, logits.size(-1)))
+            logits = logits.masked_fill(logits < v[:, -1:], -float("inf"))
+        probs = F.softmax(logits, dim=-1)
+        return torch.multinomial(probs, num_samples=1)
+
     @torch.no_grad()
-    def generate(self, idx: torch.Tensor, max_new_tokens: int, temperature: float = 1.0, topk: int | None = None):
+    def generate(self, idx: torch.Tensor, max_new_tokens: int, temperature: float = 1.0, topk: int | None = None,
+                 hip_graph: bool | None = None):
         """KV-cache sampling with a sliding window of ``block_size - 1`` cached positions
-        (reference: single-gpu/model.py:699-747)."""
+        (reference: single-gpu/model.py:699-747).
+
+        ``hip_graph`` (default: automatic) decodes from ONE captured hipGraph per token over a
+        preallocated cache when the model is on the GPU, of the GQA family, and prompt plus new
+        tokens fit the context: a decode step is a few hundred small kernels, bound by launch cost."""
         was_training = self.training
         self.eval()
+        try:
+            cfg = self.config
+            fits = idx.size(1) + max_new_tokens - 1 <= cfg.block_size and max_new_tokens >= 3
+            able = idx.is_cuda and cfg.attn in ("mha", "mqa", "gqa") and fits
+            if hip_graph is None:
+                hip_graph = able
+            self.last_decode_graphed = False      # introspection: did the last call replay a graph?
+            if hip_graph and able:
+                out = self._generate_graphed(idx, max_new_tokens, temperature, topk)
+                if out is not None:
+                    self.last_decode_graphed = True
+                    return out
+            return self._generate_eager(idx, max_new_tokens, temperature, topk)
+        finally:
+            if was_training:
+                self.train()
+
+    def _generate_graphed(self, idx, max_new_tokens, temperature, topk):
+        """Prompt through the normal forward, then one eager decode step over the static cache (lazy
+        initialisations happen outside the capture), then the same step captured once and replayed for
+        every remaining token. Returns None if the step cannot be captured."""
+        cfg = self.config
+        B, P = idx.shape
+        dev = idx.device
+        logits, _, caches = self.forward(idx)
+        static = StaticKVCache(cfg, B, cfg.block_size, dev, self.lm_head.weight.dtype)
+        static.fill(caches, P)
+        del caches
+        out = torch.empty(B, max_new_tokens, dtype=torch.int64, device=dev)
+        tok = self._sample(logits, temperature, topk)
+        out[:, :1] = tok
+        out_pos = torch.ones(1, dtype=torch.int64, device=dev)
+
+        def step():
+            lg, _, _ = self.forward(tok, kv_caches=static)
+            nxt = self._sample(lg, temperature, topk)
+            out.index_copy_(1, out_pos, nxt)
+            tok.copy_(nxt)
+            static.advance()
+            out_pos.add_(1)
+
+        step()                                   # token 2, eagerly
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as exc:                 # some op of this configuration cannot be captured
+            torch.cuda.synchronize()
+            print(f"[hip_graph] decode capture failed ({type(exc).__name__}: {exc}); decoding eagerly", flush=True)
+            return None
+        for _ in range(max_new_tokens - 2):
+            graph.replay()
+        return torch.cat((idx, out), dim=1)
+
+    def _generate_eager(self, idx, max_new_tokens, temperature, topk):
         cfg = self.config
         kv_caches = [None] * cfg.n_layer
         for i in range(max_new_tokens):
@@ -610,15 +742,5 @@ class LLM(nn.Module):
                     else:
                         kv_caches[li] = c[:, -keep:, :]
             logits, _, kv_caches = self.forward(inp, kv_caches=kv_caches)
-            logits = logits[:, -1, :].float()
-            if temperature > 0:
-                logits = logits / temperature
-            if topk is not None:
-                v, _ = torch.topk(logits, min(topk, logits.size(-1)))
-                logits[logits < v[:, [-1]]] = -float("inf")
-            probs = F.softmax(logits, dim=-1)
-            idx_next = torch.multinomial(probs, num_samples=1)
-            idx = torch.cat((idx, idx_next), dim=1)
-        if was_training:
-            self.train()
+            idx = torch.cat((idx, self._sample(logits, temperature, topk)), dim=1)
         return idx

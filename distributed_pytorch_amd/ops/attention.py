@@ -169,3 +169,18 @@ def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
         vp = F.pad(v, (0, tgt - dv))
         return _FlashAttnFn.apply(qp, kp, vp, float(scale), dropout_p, seed)[..., :dv]
     return causal_attention_eager(q, k, v, float(scale), dropout_p)
+
+
+def cached_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: torch.Tensor,
+                     scale: float | None = None) -> torch.Tensor:
+    """Inference attention over a preallocated cache: ``q [B, Tq, nh, hs]`` are the newest ``Tq`` positions,
+    ``k_cache, v_cache [B, S, nkv, hs]`` hold ``kv_len`` (int32 ``[1]`` on the device, new tokens included)
+    valid positions. The length is read by the kernel, not by the host, so the call can sit inside a
+    captured hipGraph whose replays see a growing cache. No gradient."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    if _hip_ok(q, k_cache, v_cache):
+        o, _ = ops().attn_fwd(_packed(q), k_cache, v_cache, float(scale), 0.0, None, kv_len)
+        return o
+    n = int(kv_len.item())
+    return causal_attention_eager(q, k_cache[:, :n], v_cache[:, :n], float(scale))
