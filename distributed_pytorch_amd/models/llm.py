@@ -71,14 +71,29 @@ def _drop(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
 
 # ---------------------------------------------------------------------------------------------
 class StaticKVCache:
-    """Preallocated key / value cache of the GQA family for decoding inside a captured hipGraph:
-    ``k[i], v[i] [B, S, nkv, hs]`` per layer, and the fill level as DEVICE scalars (``pos`` int64 =
-    position of the next token, ``len_after`` int32 = fill level once that token is appended), so
-    a replayed step needs no host-side shape or offset. ``advance()`` moves both by one."""
+    """Preallocated key / value cache for decoding inside a captured hipGraph: ``k[i], v[i]
+    [B, S, heads, width]`` per layer, and the fill level as DEVICE scalars (``pos`` int64 = position of
+    the next token, ``len_after`` int32 = fill level once that token is appended), so a replayed
+    step needs no host-side shape or offset. ``advance()`` moves both by one.
+
+    GQA family: ``heads = n_kv_heads``, ``width = head_size``. MLA: one latent "head"; a key row is the
+    latent (plus the rotary key for the RoPE variant), a value row the latent, both zero-padded to
+    the kernels' 64 / 128 columns (``static_width``)."""
+
+    @staticmethod
+    def static_width(config: LLMconfig) -> int | None:
+        """Row width of the cache, or None if this configuration has no static-cache decode path."""
+        if config.attn in ("mha", "mqa", "gqa"):
+            hs = config.n_embd // config.n_head
+            return hs if hs in (64, 128) else None
+        dk = config.kv_latent_dim + (config.rope_head_dim if config.pos_emb == "rope" else 0)
+        return 64 if dk <= 64 else (128 if dk <= 128 else None)
 
     def __init__(self, config: LLMconfig, batch: int, max_len: int, device, dtype):
-        hs = config.n_embd // config.n_head
-        shape = (batch, max_len, config.n_kv_heads, hs)
+        self.mla = config.attn == "mla"
+        self.width = self.static_width(config)
+        assert self.width is not None, "no static-cache decode path for this configuration"
+        shape = (batch, max_len, 1 if self.mla else config.n_kv_heads, self.width)
         self.k = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(config.n_layer)]
         self.v = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(config.n_layer)]
         self.max_len = max_len
@@ -86,10 +101,21 @@ class StaticKVCache:
         self.len_after = torch.ones(1, dtype=torch.int32, device=device)
 
     def fill(self, caches, length: int):
-        """Load the prompt's keys / values (the dynamic caches ``(B, nkv, T, hs)`` of an eager forward)."""
-        for i, (ck, cv) in enumerate(caches):
-            self.k[i][:, :length].copy_(ck.transpose(1, 2))
-            self.v[i][:, :length].copy_(cv.transpose(1, 2))
+        """Load the prompt's keys / values from the dynamic caches an eager forward returned."""
+        for i, c in enumerate(caches):
+            if not self.mla:
+                ck, cv = c                                           # (B, nkv, T, hs)
+                self.k[i][:, :length].copy_(ck.transpose(1, 2))
+                self.v[i][:, :length].copy_(cv.transpose(1, 2))
+                continue
+            if isinstance(c, dict):                                  # RoPE variant: latent + rotary key
+                lat, kr = c["c_kv"], c["k_r"].squeeze(1)             # (B, T, n_kvl), (B, T, dhr)
+                self.k[i][:, :length, 0, : lat.shape[-1]].copy_(lat)
+                self.k[i][:, :length, 0, lat.shape[-1]: lat.shape[-1] + kr.shape[-1]].copy_(kr)
+            else:
+                lat = c
+                self.k[i][:, :length, 0, : lat.shape[-1]].copy_(lat)
+            self.v[i][:, :length, 0, : lat.shape[-1]].copy_(lat)
         self.pos.fill_(length)
         self.len_after.fill_(length + 1)
 
@@ -167,6 +193,19 @@ class GQA(nn.Module):
         return not self.training and not getattr(self, "_val_run", False)
 
 
+def _mla_static_step(cache, q_eff, k_row, v_row, scale):
+    """One decode step of latent attention over a static cache: q_eff [B, 1, nh, Dk], the new key row
+    k_row [B, 1, Dk] and value row v_row [B, 1, Dv] are zero-padded to the cache width, appended at the
+    device-side position, and the context [B, 1, nh, Dv] is read back from the padded output."""
+    W = cache.k.shape[-1]
+    B = q_eff.shape[0]
+    dk, dv = k_row.shape[-1], v_row.shape[-1]
+    cache.k.index_copy_(1, cache.pos, F.pad(k_row, (0, W - dk)).view(B, 1, 1, W))
+    cache.v.index_copy_(1, cache.pos, F.pad(v_row, (0, W - dv)).view(B, 1, 1, W))
+    ctx = ops.cached_attention(F.pad(q_eff, (0, W - dk)), cache.k, cache.v, cache.len_after, scale)
+    return ctx[..., :dv]
+
+
 def _mla_attention(q_eff, k_eff, v_lat, scale, dropout_p):
     """Multi-query attention over latent keys/values: q_eff [B,T,nh,Dk], k_eff [B,Tk,1,Dk],
     v_lat [B,Tk,1,Dv] -> [B,T,nh,Dv]. Key widths up to 128 run on the flash kernels (features are
@@ -213,9 +252,13 @@ class NaiveMHLA(nn.Module):
                     self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
             k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
         new_c_kv = ops.linear(x, self.W_dkv.weight)
-        c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache, new_c_kv], dim=1)
         q = ops.linear(ops.linear(x, self.W_dq.weight), self.W_uq.weight).view(B, T, nh, hs)
         q_eff = torch.einsum("bthd,hdl->bthl", q, k_abs.to(q.dtype))          # (B, T, nh, n_kvl)
+        if isinstance(kv_cache, _StaticLayer):
+            ctx = _mla_static_step(kv_cache, q_eff, new_c_kv, new_c_kv, 1.0 / math.sqrt(hs))
+            y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
+            return y, kv_cache
+        c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache, new_c_kv], dim=1)
         ctx = _mla_attention(q_eff, c_kv.unsqueeze(2), c_kv.unsqueeze(2), 1.0 / math.sqrt(hs), p_drop)
         y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
         y = _drop(y, self.config.dropout, self.training)
@@ -268,14 +311,19 @@ class FullMHLA(nn.Module):
                     self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
             k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
         new_c_kv = ops.linear(x, self.W_dkv.weight)
-        c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache["c_kv"], new_c_kv], dim=1)
         k_r = ops.apply_rope(ops.linear(x, self.W_kr.weight).view(B, T, 1, dhr), cos_t, sin_t, pos0)
-        k_r = k_r.transpose(1, 2)                                              # (B, 1, T, dhr): cache layout
-        if kv_cache is not None:
-            k_r = torch.cat([kv_cache["k_r"], k_r], dim=2)
         q_r = ops.apply_rope(ops.linear(c_q, self.W_qr.weight).view(B, T, nh, dhr), cos_t, sin_t, pos0)
         q_nope = torch.einsum("btq,hql->bthl", c_q, k_abs.to(c_q.dtype))       # (B, T, nh, nlkv)
         q_eff = torch.cat([q_nope, q_r], dim=-1)                               # (B, T, nh, nlkv + dhr)
+        if isinstance(kv_cache, _StaticLayer):
+            k_row = torch.cat([new_c_kv, k_r.view(B, T, dhr)], dim=-1)
+            ctx = _mla_static_step(kv_cache, q_eff, k_row, new_c_kv, 1.0 / math.sqrt(hs + dhr))
+            y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
+            return y, kv_cache
+        c_kv = new_c_kv if kv_cache is None else torch.cat([kv_cache["c_kv"], new_c_kv], dim=1)
+        k_r = k_r.transpose(1, 2)                                              # (B, 1, T, dhr): cache layout
+        if kv_cache is not None:
+            k_r = torch.cat([kv_cache["k_r"], k_r], dim=2)
         k_eff = torch.cat([c_kv, k_r.squeeze(1)], dim=-1).unsqueeze(2)         # (B, Tk, 1, nlkv + dhr)
         ctx = _mla_attention(q_eff, k_eff, c_kv.unsqueeze(2), 1.0 / math.sqrt(hs + dhr), p_drop)
         y = torch.einsum("bthl,hld->bthd", ctx, v_abs.to(ctx.dtype)).reshape(B, T, C)
@@ -597,7 +645,7 @@ class LLM(nn.Module):
         if isinstance(kv_caches, StaticKVCache):
             # decode step over the preallocated cache: the position is a device scalar, so the position
             # row / rotary rows are gathered on the device and handed to the kernels as 1-row tables
-            assert T == 1 and cfg.attn in ("mha", "mqa", "gqa"), "static cache: one token per step, GQA family"
+            assert T == 1, "static cache: one token per step"
             static = kv_caches
             ptab = self._pos_table(wte.dtype, wte.device)
             x = ops.embedding(idx, wte, None if ptab is None else ptab.index_select(0, static.pos), 0)
@@ -667,14 +715,14 @@ class LLM(nn.Module):
         (reference: single-gpu/model.py:699-747).
 
         ``hip_graph`` (default: automatic) decodes from ONE captured hipGraph per token over a
-        preallocated cache when the model is on the GPU, of the GQA family, and prompt plus new
-        tokens fit the context: a decode step is a few hundred small kernels, bound by launch cost."""
+        preallocated cache when the model is on the GPU, its key rows fit the flash kernels (head size
+        64 / 128, or an MLA latent key of at most 128 columns) and prompt plus new tokens fit the context: a decode step is a few hundred small kernels, bound by launch cost."""
         was_training = self.training
         self.eval()
         try:
             cfg = self.config
             fits = idx.size(1) + max_new_tokens - 1 <= cfg.block_size and max_new_tokens >= 3
-            able = idx.is_cuda and cfg.attn in ("mha", "mqa", "gqa") and fits
+            able = idx.is_cuda and StaticKVCache.static_width(cfg) is not None and fits
             if hip_graph is None:
                 hip_graph = able
             self.last_decode_graphed = False      # introspection: did the last call replay a graph?

@@ -197,7 +197,8 @@ def test_dropout_trains_on_the_hip_path(scope):
         assert (g - other).norm() <= 2e-2 * g.norm() + 1e-6, n
 
 
-@pytest.mark.parametrize("name", ["gpt2", "gqa_rope_swiglu", "mqa_sin", "moe"])
+@pytest.mark.parametrize("name", ["gpt2", "gqa_rope_swiglu", "mqa_sin", "moe", "mla_rope_flash", "mla_naive_flash",
+                                  "mla_rope_small_latent"])
 def test_graphed_decode_matches_eager_decode(name):
     """generate() replaying one captured decode step per token (static KV cache, device-side positions)
     produces the tokens of the eager cache path; top-k 1 makes sampling deterministic."""
