@@ -285,6 +285,12 @@ Tensor gelu_bwd(const Tensor& dy, const Tensor& x) {
   dpa::gelu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), is_bf16(x), cur_stream());
   return dx;
 }
+void spin(int64_t blocks, int64_t usec, Tensor sink) {
+  TORCH_CHECK(sink.is_cuda() && sink.scalar_type() == at::kFloat && sink.numel() >= 1 && blocks <= 256 && usec <= 20000,
+              "spin: fp32 sink on the GPU, at most 256 blocks and 20 ms");
+  dpa::spin((int)blocks, (int)usec, sink.data_ptr<float>(), cur_stream());
+}
+
 Tensor act_fwd(const Tensor& x, int64_t kind) {
   check_act(x, "x");
   TORCH_CHECK(x.numel() % 8 == 0 && kind >= 0 && kind < dpa::act_kinds(), "act_fwd: bad size or kind");
@@ -781,6 +787,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("pos_bwd(Tensor dout, Tensor(a!) dpos, int pos0) -> ()");
   m.def("gelu_fwd(Tensor x) -> Tensor");
   m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
+  m.def("spin(int blocks, int usec, Tensor(a!) sink) -> ()");
   m.def("act_fwd(Tensor x, int kind) -> Tensor");
   m.def("act_bwd(Tensor dy, Tensor x, int kind) -> Tensor");
   m.def("swiglu_fwd(Tensor h) -> Tensor");
@@ -826,6 +833,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("pos_bwd", pos_bwd);
   m.impl("gelu_fwd", gelu_fwd);
   m.impl("gelu_bwd", gelu_bwd);
+  m.impl("spin", spin);
   m.impl("act_fwd", act_fwd);
   m.impl("act_bwd", act_bwd);
   m.impl("swiglu_fwd", swiglu_fwd);

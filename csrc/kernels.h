@@ -138,6 +138,8 @@ void moe_plan(const long long* idx, long long npairs, int E, int nrb, int pad, i
 // ---- Column sums (bias gradients) ----------------------------------------------------------
 // out[N] (fp32, caller-zeroed) += column sums of x[M, N] (row stride ld elements, N % 8 == 0).
 void colsum(const void* x, float* out, long long M, int N, long long ld, bool is_bf16, hipStream_t st);
+// Benchmark aid: occupy `blocks` CUs for about `usec` microseconds.
+void spin(int blocks, int usec, float* sink, hipStream_t st);
 
 // ---- RoPE -------------------------------------------------------------------------------
 // In-place interleaved-pair rotation of `nheads` heads of size hs at x + t*ts (+ b*bs), using

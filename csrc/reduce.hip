@@ -52,4 +52,23 @@ void colsum(const void* x, float* out, long long M, int N, long long ld, bool is
     hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)x, out, M, N, ld, (int)rpb);
 }
 
+// Benchmark aid: `blocks` workgroups that each hold a CU busy for about `usec` microseconds (a stand-in
+// for a collective's kernels when the effect of lost CUs on the compute kernels is measured on one GPU).
+// Every wave leaves after the deadline or after a bounded number of polls, whichever comes first.
+__global__ __launch_bounds__(256) void spin_kernel(long long ticks, float* sink) {
+  const long long t0 = wall_clock64();
+  float acc = 0.f;
+  for (int i = 0; i < (1 << 24); ++i) {
+    acc += 1e-9f * (float)i;
+    if ((i & 63) == 0 && wall_clock64() - t0 >= ticks) break;
+  }
+  if (acc == -1.f) sink[0] = acc;
+}
+
+void spin(int blocks, int usec, float* sink, hipStream_t st) {
+  if (blocks <= 0 || usec <= 0) return;
+  // wall_clock64 counts at 100 MHz on this part
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, st, (long long)usec * 100, sink);
+}
+
 }  // namespace dpa

@@ -70,6 +70,24 @@ class DDPEngine(Engine):
             return
         self._launched[gi] = True
         self._works.append(self._reduce_group(gi))
+        self._emulate_comm_kernels()
+
+    def _emulate_comm_kernels(self):
+        """DPA_EMULATE_COMM="<CUs>,<microseconds>" (benchmark aid, one GPU): with every bucket launch, hold
+        that many CUs busy for that long on a side stream, as the kernels of a multi-GPU collective
+        would, to measure how the backward kernels react to losing CUs."""
+        import os
+        spec = os.environ.get("DPA_EMULATE_COMM", "")
+        if not spec or self.device.type != "cuda":
+            return
+        from .._ext import ops
+        blocks, usec = (int(v) for v in spec.split(","))
+        if not hasattr(self, "_emu"):
+            self._emu = (torch.cuda.Stream(device=self.device), torch.zeros(1, device=self.device))
+        side, sink = self._emu
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            ops().spin(blocks, usec, sink)
 
     def _reduce_group(self, gi: int):
         return comm.all_reduce(self.groups[gi].grad, group=self.group, async_op=True)
