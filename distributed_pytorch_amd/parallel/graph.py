@@ -15,7 +15,11 @@ What makes the step capturable:
     tensor that is refreshed before each replay, because kernel arguments are frozen at capture;
   * gradients accumulate into the engine's flat buffers, whose addresses never change.
 
-Collectives are not captured: the graphed step is for engines that issue none (one GPU).
+The plain engine and the data-parallel engine can be captured. For DDP the bucketed all-reduces are
+part of the graph (RCCL collectives are capturable; they run on the communicator's stream, which the
+capture follows through the events that order it with the compute stream), so a launch-bound model
+keeps its advantage on several GPUs. The sharded engines (ZeRO, FSDP, EP) are not captured: their
+storage is resized and their collectives depend on host-side bookkeeping inside a step.
 """
 from __future__ import annotations
 
@@ -31,7 +35,8 @@ class GraphedTrainStep:
 
     def __init__(self, engine, accum: int = 1, grad_clip: float = 1.0, warmup: int = 3):
         assert engine.device.type == "cuda", "hipGraph capture needs the GPU"
-        assert not engine._dist, "the graphed step does not capture collectives (single-GPU engines only)"
+        assert (not engine._dist) or type(engine).name == "ddp", \
+            "only the plain and the data-parallel engine are captured"
         self.engine = engine
         self.accum = int(accum)
         self.grad_clip = float(grad_clip)
@@ -58,6 +63,7 @@ class GraphedTrainStep:
         eng.zero_grad()
         loss = None
         for i in range(self.accum):
+            eng.require_backward_grad_sync = i == self.accum - 1     # DDP: reduce with the last micro-batch
             _, loss, _ = eng(xs[i], ys[i])
             loss = loss / self.accum
             loss.backward()

@@ -137,12 +137,15 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
 
     # Launch-bound steps (few tokens per step) are replayed from one hipGraph, the role torch.compile
     # plays in the reference trainer (reference: single-gpu/train.py:262-266). "auto" turns it on for
-    # one GPU and at most 32K tokens per step; a failed capture falls back to eager.
+    # one GPU and at most 32K tokens per step; "on" also captures the data-parallel engine (all-reduces
+    # included); a failed capture falls back to eager.
     graphed = None
     mode_g = str(tc.hip_graph).lower()
     want_graph = mode_g in ("on", "true", "1") or (
         mode_g == "auto" and tc.total_batch_size <= 32768 and not tc.profile)
-    if want_graph and device.type == "cuda" and not engine._dist and type(engine).name == "single":
+    on = mode_g in ("on", "true", "1")
+    capturable = (not engine._dist and type(engine).name == "single") or (on and type(engine).name == "ddp")
+    if want_graph and device.type == "cuda" and capturable:
         from .parallel.graph import GraphedTrainStep
         graphed = GraphedTrainStep(engine, grad_accum_steps, tc.grad_clip)
         say("Using hipGraph capture of the optimizer step")

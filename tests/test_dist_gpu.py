@@ -157,3 +157,42 @@ def test_two_ranks_share_the_gpu_every_engine_agrees():
     ref = losses["ddp"]
     for mode, v in losses.items():
         assert abs(v - ref) < 5e-3 * abs(ref), losses
+
+
+def test_graphed_ddp_step_captures_the_all_reduces(one_rank_group):
+    """The data-parallel step, bucketed all-reduces included, replayed from one hipGraph follows the
+    eager DDP trajectory."""
+    from distributed_pytorch_amd.config import LLMconfig
+    from distributed_pytorch_amd.models.llm import LLM
+    from distributed_pytorch_amd.parallel.ddp import DDPEngine
+    from distributed_pytorch_amd.parallel.graph import GraphedTrainStep
+    cfg = LLMconfig(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="mha",
+                    pos_emb="learn", non_linearity="gelu").finalize()
+    torch.manual_seed(5)
+    data = [torch.randint(0, cfg.vocab_size, (2, 4, 256), device="cuda") for _ in range(8)]
+
+    def run(graph):
+        torch.manual_seed(1)
+        eng = DDPEngine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3, bucket_mb=0.5)
+        gs = GraphedTrainStep(eng, accum=2, grad_clip=1.0, warmup=2) if graph else None
+        out = []
+        for xb in data:
+            batches = [(xb[i], xb[i].roll(-1, 1)) for i in range(2)]
+            if graph:
+                out.append(gs.step(batches, 1e-3).item())
+            else:
+                eng.zero_grad()
+                for i, (bx, by) in enumerate(batches):
+                    eng.require_backward_grad_sync = i == 1
+                    _, loss, _ = eng(bx, by)
+                    (loss / 2).backward()
+                eng.clip_grad_norm_(1.0)
+                eng.step(1e-3)
+                out.append(loss.item())
+        return out, gs
+
+    eager, _ = run(False)
+    graphed, gs = run(True)
+    assert gs.graph is not None and not gs.failed, "the DDP step must be captured"
+    for a, b in zip(graphed, eager):
+        assert abs(a - b) < 2e-2 * abs(b), (graphed, eager)
