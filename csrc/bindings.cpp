@@ -285,6 +285,22 @@ Tensor gelu_bwd(const Tensor& dy, const Tensor& x) {
   dpa::gelu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), is_bf16(x), cur_stream());
   return dx;
 }
+Tensor sample_topk(const Tensor& logits, double temperature, int64_t topk, const Tensor& seed) {
+  TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && logits.stride(1) == 1 &&
+                  (logits.scalar_type() == at::kBFloat16 || logits.scalar_type() == at::kFloat),
+              "sample_topk: logits [rows, V] bf16/fp32 with unit inner stride on the GPU");
+  TORCH_CHECK(seed.is_cuda() && seed.scalar_type() == at::kLong && seed.numel() == 1, "sample_topk: int64 [1] seed on the GPU");
+  TORCH_CHECK(logits.size(1) < (1 << 30) && dpa::sample_topk_ok((int)logits.size(1)) &&
+                  (logits.stride(0) * logits.element_size()) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(logits.data_ptr()) % 16 == 0,
+              "sample_topk: vocabulary must be a multiple of 8, at most 57344, rows 16-byte aligned");
+  Tensor out = at::empty({logits.size(0), 1}, logits.options().dtype(at::kLong));
+  dpa::sample_topk(logits.data_ptr(), logits.stride(0), (int)logits.size(0), (int)logits.size(1), (float)temperature,
+                   (int)std::max<int64_t>(topk, 0), (const long long*)seed.data_ptr<int64_t>(),
+                   (long long*)out.data_ptr<int64_t>(), is_bf16(logits), cur_stream());
+  return out;
+}
+
 void spin(int64_t blocks, int64_t usec, Tensor sink) {
   TORCH_CHECK(sink.is_cuda() && sink.scalar_type() == at::kFloat && sink.numel() >= 1 && blocks <= 256 && usec <= 20000,
               "spin: fp32 sink on the GPU, at most 256 blocks and 20 ms");
@@ -787,6 +803,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("pos_bwd(Tensor dout, Tensor(a!) dpos, int pos0) -> ()");
   m.def("gelu_fwd(Tensor x) -> Tensor");
   m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
+  m.def("sample_topk(Tensor logits, float temperature, int topk, Tensor seed) -> Tensor");
   m.def("spin(int blocks, int usec, Tensor(a!) sink) -> ()");
   m.def("act_fwd(Tensor x, int kind) -> Tensor");
   m.def("act_bwd(Tensor dy, Tensor x, int kind) -> Tensor");
@@ -833,6 +850,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("pos_bwd", pos_bwd);
   m.impl("gelu_fwd", gelu_fwd);
   m.impl("gelu_bwd", gelu_bwd);
+  m.impl("sample_topk", sample_topk);
   m.impl("spin", spin);
   m.impl("act_fwd", act_fwd);
   m.impl("act_bwd", act_bwd);

@@ -138,6 +138,12 @@ void moe_plan(const long long* idx, long long npairs, int E, int nrb, int pad, i
 // ---- Column sums (bias gradients) ----------------------------------------------------------
 // out[N] (fp32, caller-zeroed) += column sums of x[M, N] (row stride ld elements, N % 8 == 0).
 void colsum(const void* x, float* out, long long M, int N, long long ld, bool is_bf16, hipStream_t st);
+// out[row] = one token drawn from softmax(logits[row] / temperature) restricted to the top-k logits
+// (topk <= 0: no restriction; temperature <= 0: 1). The uniform variate comes from a hash of *seed and the row.
+// V % 8 == 0, V <= 57344 (sample_topk_ok), rows 16-byte aligned.
+bool sample_topk_ok(int V);
+void sample_topk(const void* logits, long long ld, int rows, int V, float temperature, int topk, const long long* seed,
+                 long long* out, bool is_bf16, hipStream_t st);
 // Benchmark aid: occupy `blocks` CUs for about `usec` microseconds.
 void spin(int blocks, int usec, float* sink, hipStream_t st);
 

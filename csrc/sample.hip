@@ -1,0 +1,193 @@
+// Next-token sampling in one kernel (gfx950): temperature, top-k filter, softmax and one multinomial
+// draw per row. One workgroup of 1024 threads per row; the row (V <= 57344 logits) is loaded once with
+// coalesced 16-byte accesses and stays in registers (packed bf16) for all the passes:
+//   1. row maximum;
+//   2. the k-th largest logit by a bitwise search on the order-preserving integer image of the floats
+//      (one count-and-reduce per significant bit: 16 for bf16 logits, 32 for fp32), which gives the same
+//      keep set as `logits < topk(logits, k).values[:, -1]` masking, ties included;
+//   3. per-thread partial sums of exp((x - max) / T) over the kept logits, a scan over the threads, and a
+//      walk of the one thread's registers in which u * total falls (u uniform in [0, 1) from a hash of the
+//      seed and the row). The order of the walk is a fixed permutation of the vocabulary, which a
+//      multinomial draw does not care about.
+// Replaces the topk / masked_fill / softmax / multinomial chain of the reference's generate()
+// (reference: single-gpu/model.py:733-745) with a single launch inside the captured decode step.
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+constexpr int kSampleThreads = 1024;
+constexpr int kSampleVecs = 7;   // 8-element vectors per thread: V <= 1024 * 7 * 8
+
+__device__ __forceinline__ unsigned smix32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+
+// Monotone map float -> uint32 (larger float, larger key). NaN sorts above +inf; callers feed finite logits.
+__device__ __forceinline__ unsigned order_key(float x) {
+  const unsigned b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Sum of an int over the workgroup (every thread gets the result). `red` holds 16 ints of LDS.
+__device__ __forceinline__ int block_count(int v, int* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < kSampleThreads / 64; ++i) r += red[i];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __restrict__ logits, long long ld, int V,
+                                                                    float inv_temp, int topk,
+                                                                    const long long* __restrict__ seed,
+                                                                    long long* __restrict__ out) {
+  __shared__ float red[16];
+  __shared__ int ired[16];
+  __shared__ float wave_tot[kSampleThreads / 64];
+  __shared__ int chosen;
+  __shared__ float chosen_rest;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* x = logits + (long long)row * ld;
+  const int nvec = V >> 3;   // V % 8 == 0 (host-checked)
+
+  // vector k of this thread is row vector tid + k * 1024 (coalesced); absent vectors hold -inf
+  Vec8<T> v[kSampleVecs];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < kSampleVecs; ++k) {
+    const int i = tid + k * kSampleThreads;
+    if (i < nvec) {
+      v[k].load(x + (long long)i * 8);
+      float e[8];
+      v[k].get(e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, e[j]);
+    }
+  }
+  mx = block_max(mx, red);
+
+  unsigned thr_key = 0u;   // keep everything
+  if (topk > 0 && topk < V) {
+    // largest key such that at least `topk` logits are >= it: the key of the k-th largest logit
+    constexpr int kLowBit = sizeof(T) == 2 ? 16 : 0;   // bf16 images have no low 16 bits
+    unsigned prefix = 0u;
+    for (int bit = 31; bit >= kLowBit; --bit) {
+      const unsigned cand = prefix | (1u << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < kSampleVecs; ++k) {
+        if (tid + k * kSampleThreads < nvec) {
+          float e[8];
+          v[k].get(e);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cnt += order_key(e[j]) >= cand ? 1 : 0;
+        }
+      }
+      if (block_count(cnt, ired) >= topk) prefix = cand;
+    }
+    thr_key = prefix;
+  }
+
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSampleVecs; ++k) {
+    if (tid + k * kSampleThreads < nvec) {
+      float e[8];
+      v[k].get(e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (order_key(e[j]) >= thr_key) s += __expf((e[j] - mx) * inv_temp);
+    }
+  }
+  // exclusive prefix of s over the threads (thread order = walk order) and the total
+  float incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (tid == 0) chosen = -1;
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  float base = 0.f, total = 0.f;
+#pragma unroll
+  for (int w = 0; w < kSampleThreads / 64; ++w) {
+    if (w < wid) base += wave_tot[w];
+    total += wave_tot[w];
+  }
+  const float excl = base + incl - s;
+  const unsigned long long sd = (unsigned long long)*seed;
+  const unsigned h = smix32((unsigned)sd ^ smix32((unsigned)(sd >> 32) + 0x9E3779B9u * (unsigned)(row + 1)));
+  const float target = (float)(h >> 8) * (1.0f / 16777216.0f) * total;   // u in [0, 1) with 24 random bits
+  if (s > 0.f && target >= excl && target < excl + s) {
+    chosen = tid;                 // intervals are disjoint: at most one thread qualifies
+    chosen_rest = target - excl;
+  }
+  __syncthreads();
+  if (chosen < 0) {
+    // rounding put the target at or past the last interval: the last thread that kept anything walks to its end
+    const int cand = s > 0.f ? tid : -1;
+    int best = cand;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+    if (lane == 0) ired[wid] = best;
+    __syncthreads();
+    if (tid == 0) {
+      int b = -1;
+      for (int w = 0; w < kSampleThreads / 64; ++w) b = max(b, ired[w]);
+      chosen = b < 0 ? 0 : b;
+      chosen_rest = INFINITY;
+    }
+    __syncthreads();
+  }
+  if (tid == chosen) {
+    const float rest = chosen_rest;
+    float cum = 0.f;
+    int pick = -1, last = 0;
+#pragma unroll
+    for (int k = 0; k < kSampleVecs; ++k) {
+      const int i = tid + k * kSampleThreads;
+      if (i < nvec && pick < 0) {
+        float e[8];
+        v[k].get(e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (pick < 0 && order_key(e[j]) >= thr_key) {
+            last = i * 8 + j;
+            cum += __expf((e[j] - mx) * inv_temp);
+            if (cum > rest) pick = last;
+          }
+        }
+      }
+    }
+    out[row] = pick >= 0 ? pick : last;
+  }
+}
+
+bool sample_topk_ok(int V) { return V >= 8 && V % 8 == 0 && V <= kSampleThreads * kSampleVecs * 8; }
+
+void sample_topk(const void* logits, long long ld, int rows, int V, float temperature, int topk, const long long* seed,
+                 long long* out, bool is_bf16, hipStream_t st) {
+  if (rows == 0) return;
+  const float inv_temp = temperature > 0.f ? 1.f / temperature : 1.f;
+  if (is_bf16)
+    hipLaunchKernelGGL((sample_topk_kernel<bf16_t>), dim3(rows), dim3(kSampleThreads), 0, st, (const bf16_t*)logits, ld, V,
+                       inv_temp, topk, seed, out);
+  else
+    hipLaunchKernelGGL((sample_topk_kernel<float>), dim3(rows), dim3(kSampleThreads), 0, st, (const float*)logits, ld, V,
+                       inv_temp, topk, seed, out);
+}
+
+}  // namespace dpa

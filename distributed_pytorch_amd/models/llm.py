@@ -696,17 +696,12 @@ class LLM(nn.Module):
 
     # ---- generation -----------------------------------------------------------------------
     @staticmethod
-    def _sample(logits: torch.Tensor, temperature: float, topk: int | None) -> torch.Tensor:
-        """Next token ``[B, 1]`` from the last position's logits (temperature, top-k, multinomial);
-        no data-dependent host work, so it can be captured in a hipGraph."""
-        logits = logits[:, -1, :].float()
-        if temperature > 0:
-            logits = logits / temperature
-        if topk is not None:
-            v, _ = torch.topk(logits, min(topk, logits.size(-1)))
-            logits = logits.masked_fill(logits < v[:, -1:], -float("inf"))
-        probs = F.softmax(logits, dim=-1)
-        return torch.multinomial(probs, num_samples=1)
+    def _sample(logits: torch.Tensor, temperature: float, topk: int | None, fused: bool = False) -> torch.Tensor:
+        """Next token ``[B, 1]`` from the last position's logits (temperature, top-k, multinomial); no
+        data-dependent host work, so it can be captured in a hipGraph. ``fused``: the one-kernel sampler
+        (same distribution, its own random stream) instead of the chain of stock ops."""
+        last = logits[:, -1, :]
+        return ops.sample_fused(last, temperature, topk) if fused else ops.sample_eager(last, temperature, topk)
 
     @torch.no_grad()
     def generate(self, idx: torch.Tensor, max_new_tokens: int, temperature: float = 1.0, topk: int | None = None,
@@ -754,7 +749,7 @@ class LLM(nn.Module):
 
         def step():
             lg, _, _ = self.forward(tok, kv_caches=static)
-            nxt = self._sample(lg, temperature, topk)
+            nxt = self._sample(lg, temperature, topk, fused=True)
             out.index_copy_(1, out_pos, nxt)
             tok.copy_(nxt)
             static.advance()

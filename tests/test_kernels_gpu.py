@@ -681,3 +681,49 @@ def test_cached_attention_reads_the_fill_level_from_the_device(nh, nkv, hs):
         o = ops.cached_attention(q, kc, vc, kv_len, scale)
         ref = ops.causal_attention_eager(q.float(), kc[:, :n].float(), vc[:, :n].float(), scale)
         assert rel_err(o, ref) < 1e-2, n
+
+
+def test_fused_sampler_top1_is_argmax_and_samples_stay_in_the_top_k():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float32):
+        logits = (3 * torch.randn(33, 50304, device=DEV)).to(dtype)
+        assert torch.equal(ops.sample_fused(logits, 1.0, 1)[:, 0], logits.float().argmax(-1))
+        k = 50
+        kth = torch.topk(logits.float(), k).values[:, -1:]
+        for _ in range(4):
+            tok = ops.sample_fused(logits, 0.8, k)
+            assert tok.shape == (33, 1) and tok.dtype == torch.int64
+            assert (logits.float().gather(1, tok) >= kth).all()
+    # a short row with k larger than the row (kernel), and an odd-sized row (stock-op fallback)
+    for width in (16, 13):
+        small = torch.randn(5, width, device=DEV)
+        tok = ops.sample_fused(small, 1.0, 100)
+        assert int(tok.min()) >= 0 and int(tok.max()) < width
+
+
+@pytest.mark.parametrize("topk,temperature", [(None, 1.0), (8, 0.7)])
+def test_fused_sampler_follows_the_softmax_distribution(topk, temperature):
+    """Many rows with the same logits: the empirical token frequencies match softmax(top-k(logits) / T)."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(1)
+    V, rows = 40, 32768
+    base = 2 * torch.randn(V, device=DEV)
+    logits = base.expand(rows, V).contiguous()
+    x = base / temperature
+    if topk is not None:
+        x = x.masked_fill(x < torch.topk(x, topk).values[-1], -float("inf"))
+    want = torch.softmax(x, -1)
+    counts = torch.zeros(V, device=DEV)
+    n_draws = 4
+    for _ in range(n_draws):
+        tok = ops.sample_fused(logits, temperature, topk)
+        counts += torch.bincount(tok[:, 0], minlength=V).float()
+    got = counts / (rows * n_draws)
+    assert (got[want == 0] == 0).all()
+    assert (got - want).abs().max().item() < 6e-3, (got - want).abs().max().item()
+    # a fixed seed reproduces the draw, another seed changes it
+    seed = torch.tensor([99], dtype=torch.int64, device=DEV)
+    a = ops.sample_fused(logits, temperature, topk, seed)
+    assert torch.equal(a, ops.sample_fused(logits, temperature, topk, seed))
+    assert not torch.equal(a, ops.sample_fused(logits, temperature, topk, seed + 1))
