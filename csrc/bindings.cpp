@@ -245,6 +245,25 @@ Tensor embed_fwd(const Tensor& idx, const Tensor& wte, const std::optional<Tenso
   return out;
 }
 
+// Caches [B, S, H, hs] contiguous; new rows [B, 1, H, hs] with packed heads (any batch stride); pos int64 [1].
+void kv_append(Tensor k_cache, Tensor v_cache, const Tensor& k_new, const Tensor& v_new, const Tensor& pos) {
+  TORCH_CHECK(k_cache.is_cuda() && k_cache.scalar_type() == at::kBFloat16 && k_cache.is_contiguous() &&
+                  k_cache.dim() == 4 && v_cache.sizes() == k_cache.sizes() && v_cache.is_contiguous() &&
+                  v_cache.scalar_type() == at::kBFloat16,
+              "kv_append: contiguous bf16 caches [B, S, H, hs]");
+  const int64_t B = k_cache.size(0), S = k_cache.size(1), H = k_cache.size(2), hs = k_cache.size(3), W = H * hs;
+  for (const Tensor* t : {&k_new, &v_new}) {
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kBFloat16 && t->dim() == 4 && t->size(0) == B && t->size(1) == 1 &&
+                    t->size(2) == H && t->size(3) == hs && t->stride(3) == 1 && (H == 1 || t->stride(2) == hs) &&
+                    t->stride(0) % 8 == 0 && reinterpret_cast<uintptr_t>(t->data_ptr()) % 16 == 0,
+                "kv_append: new rows [B, 1, H, hs], packed heads, 16-byte aligned");
+  }
+  TORCH_CHECK(W % 8 == 0 && pos.is_cuda() && pos.scalar_type() == at::kLong && pos.numel() == 1, "kv_append: pos int64 [1]");
+  dpa::kv_append(k_cache.data_ptr(), v_cache.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),
+                 (const long long*)pos.data_ptr<int64_t>(), (int)B, (int)S, (int)W, k_new.stride(0), v_new.stride(0),
+                 cur_stream());
+}
+
 void embed_bwd(const Tensor& dout, const Tensor& ids_sorted, const Tensor& perm, Tensor dwte) {
   check_act(dout, "dout");
   check_act(dwte, "dwte");
@@ -803,6 +822,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("pos_bwd(Tensor dout, Tensor(a!) dpos, int pos0) -> ()");
   m.def("gelu_fwd(Tensor x) -> Tensor");
   m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
+  m.def("kv_append(Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor k_new, Tensor v_new, Tensor pos) -> ()");
   m.def("sample_topk(Tensor logits, float temperature, int topk, Tensor seed) -> Tensor");
   m.def("spin(int blocks, int usec, Tensor(a!) sink) -> ()");
   m.def("act_fwd(Tensor x, int kind) -> Tensor");
@@ -850,6 +870,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("pos_bwd", pos_bwd);
   m.impl("gelu_fwd", gelu_fwd);
   m.impl("gelu_bwd", gelu_bwd);
+  m.impl("kv_append", kv_append);
   m.impl("sample_topk", sample_topk);
   m.impl("spin", spin);
   m.impl("act_fwd", act_fwd);

@@ -153,6 +153,34 @@ __global__ __launch_bounds__(256) void pos_bwd_kernel(const T* __restrict__ dout
   }
 }
 
+// Decode-time cache append: row `*pos` of k_cache / v_cache [B, S, W] (W = heads * head size) receives the new
+// key / value row of every batch element; the position is read from device memory so the launch can be
+// replayed from a hipGraph. Positions outside [0, S) write nothing.
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(T* __restrict__ kc, T* __restrict__ vc, const T* __restrict__ kn,
+                                                        const T* __restrict__ vn, const long long* __restrict__ pos,
+                                                        int B, int S, int W, long long kn_bs, long long vn_bs) {
+  const long long p = *pos;
+  if (p < 0 || p >= S) return;
+  const int wvec = W >> 3;
+  const int total = B * wvec;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / wvec, c = (i - b * wvec) * 8;
+    const long long dst = ((long long)b * S + p) * W + c;
+    *reinterpret_cast<u32x4*>(kc + dst) = *reinterpret_cast<const u32x4*>(kn + b * kn_bs + c);
+    *reinterpret_cast<u32x4*>(vc + dst) = *reinterpret_cast<const u32x4*>(vn + b * vn_bs + c);
+  }
+}
+
+void kv_append(void* kc, void* vc, const void* kn, const void* vn, const long long* pos, int B, int S, int W,
+               long long kn_bs, long long vn_bs, hipStream_t st) {
+  if (B == 0) return;
+  int blocks = (B * (W >> 3) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL((kv_append_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (bf16_t*)kc, (bf16_t*)vc,
+                     (const bf16_t*)kn, (const bf16_t*)vn, pos, B, S, W, kn_bs, vn_bs);
+}
+
 static int ew_grid(long long nthreads) {
   long long b = (nthreads + 255) / 256;
   if (b < 1) b = 1;

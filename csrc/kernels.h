@@ -36,6 +36,9 @@ void xent(int mode, void* logits, bool is_bf16, const long long* targets, float*
 // ---- Embedding -------------------------------------------------------------------------
 void embed_fwd(const long long* idx, const void* wte, const void* pos, void* out, long long N, int T_len, int pos0,
                int C, long long V, bool is_bf16, hipStream_t st);
+// k_cache / v_cache [B, S, W] (bf16) row *pos <- kn / vn [B, W] (batch strides kn_bs / vn_bs, 16-byte aligned rows).
+void kv_append(void* kc, void* vc, const void* kn, const void* vn, const long long* pos, int B, int S, int W,
+               long long kn_bs, long long vn_bs, hipStream_t st);
 int embed_bwd_chunks(long long N);  // scratch = 2 * chunks * C floats
 void embed_bwd(const void* dout, const long long* ids_sorted, const long long* perm, void* dwte, float* scratch,
                long long N, int C, long long V, bool is_bf16, hipStream_t st);

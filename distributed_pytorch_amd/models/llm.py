@@ -168,8 +168,7 @@ class GQA(nn.Module):
         if isinstance(kv_cache, _StaticLayer):
             # one new token appended in place at the device-side position, attention over the filled part
             q, k, v = ops.split_qkv(qkv, nh, nkv)
-            kv_cache.k.index_copy_(1, kv_cache.pos, k)
-            kv_cache.v.index_copy_(1, kv_cache.pos, v)
+            ops.kv_append(kv_cache.k, kv_cache.v, k, v, kv_cache.pos)
             y = ops.cached_attention(q, kv_cache.k, kv_cache.v, kv_cache.len_after)
             new_cache = kv_cache
         elif kv_cache is None and not self._want_cache():
@@ -200,8 +199,8 @@ def _mla_static_step(cache, q_eff, k_row, v_row, scale):
     W = cache.k.shape[-1]
     B = q_eff.shape[0]
     dk, dv = k_row.shape[-1], v_row.shape[-1]
-    cache.k.index_copy_(1, cache.pos, F.pad(k_row, (0, W - dk)).view(B, 1, 1, W))
-    cache.v.index_copy_(1, cache.pos, F.pad(v_row, (0, W - dv)).view(B, 1, 1, W))
+    ops.kv_append(cache.k, cache.v, F.pad(k_row, (0, W - dk)).view(B, 1, 1, W),
+                  F.pad(v_row, (0, W - dv)).view(B, 1, 1, W), cache.pos)
     ctx = ops.cached_attention(F.pad(q_eff, (0, W - dk)), cache.k, cache.v, cache.len_after, scale)
     return ctx[..., :dv]
 

@@ -2,7 +2,7 @@
 implementation that is used only for CPU tensors (plumbing tests) or unsupported shapes."""
 from .activation import gelu, get_activation, swiglu
 from .attention import (cached_attention, causal_attention, causal_attention_eager, causal_self_attention_qkv, dropout_keep_mask,
-                        split_qkv)
+                        kv_append, split_qkv)
 from .embedding import embedding
 from .linear import linear, weight_grad, wgrad_supported
 from .loss import IGNORE_INDEX, cross_entropy, linear_cross_entropy, vocab_parallel_cross_entropy
@@ -15,7 +15,7 @@ from .rope import apply_rope, rope_inplace_, rope_tables
 from .sampling import sample_eager, sample_fused
 
 __all__ = [
-    "gelu", "swiglu", "get_activation", "cached_attention", "causal_attention", "causal_attention_eager", "causal_self_attention_qkv", "dropout_keep_mask",
+    "gelu", "swiglu", "get_activation", "cached_attention", "causal_attention", "causal_attention_eager", "causal_self_attention_qkv", "dropout_keep_mask", "kv_append",
     "split_qkv", "embedding", "cross_entropy", "linear_cross_entropy", "vocab_parallel_cross_entropy",
     "IGNORE_INDEX", "layer_norm", "add_layer_norm", "adamw_step", "sumsq", "apply_rope", "rope_inplace_",
     "rope_tables", "linear", "weight_grad", "wgrad_supported", "grouped_experts", "grouped_experts_eager",

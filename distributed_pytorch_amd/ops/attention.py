@@ -184,3 +184,20 @@ def cached_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         return o
     n = int(kv_len.item())
     return causal_attention_eager(q, k_cache[:, :n], v_cache[:, :n], float(scale))
+
+
+def kv_append(k_cache: torch.Tensor, v_cache: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor,
+              pos: torch.Tensor) -> None:
+    """Write the new key / value rows ``[B, 1, H, hs]`` at row ``pos`` (int64 ``[1]`` on the device) of the
+    preallocated caches ``[B, S, H, hs]``: one launch, position read on the device."""
+    ok = (use_hip(k_cache, k_new) and k_cache.dtype == torch.bfloat16 and k_new.dtype == torch.bfloat16
+          and k_cache.is_contiguous() and v_cache.is_contiguous() and (k_cache.shape[2] * k_cache.shape[3]) % 8 == 0)
+    if ok:
+        for t in (k_new, v_new):
+            ok = ok and (t.stride(3) == 1 and (t.shape[2] == 1 or t.stride(2) == t.shape[3]) and t.stride(0) % 8 == 0
+                         and t.data_ptr() % 16 == 0)
+    if ok:
+        ops().kv_append(k_cache, v_cache, k_new, v_new, pos)
+    else:
+        k_cache.index_copy_(1, pos, k_new)
+        v_cache.index_copy_(1, pos, v_new)
