@@ -19,6 +19,13 @@ VARIANTS = {
     "moe_aux": dict(attn="mha", pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=6, n_shared=1, n_act=3),
     "moe_auxfree": dict(attn="gqa", n_kv_heads=2, pos_emb="rope", non_linearity="gelu", moe=True, n_exp=5,
                         n_shared=2, n_act=4, aux_free=True),
+    "mla_rope_moe_auxfree": dict(attn="mla", pos_emb="rope", q_latent_dim=16, kv_latent_dim=24, rope_head_dim=8,
+                                 non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2, aux_free=True),
+    "gpt2_mish": dict(attn="mha", pos_emb="learn", non_linearity="mish"),
+    "gqa_sin_lrelu": dict(attn="gqa", n_kv_heads=1, pos_emb="sin", non_linearity="lrelu"),
+    "mha_rope_tanh": dict(attn="mha", pos_emb="rope", non_linearity="tanh"),
+    "mla_naive_unknown_act": dict(attn="mla", pos_emb="sin", q_latent_dim=16, kv_latent_dim=24,
+                                  non_linearity="no_such_activation"),      # falls back to GELU like the reference
 }
 
 
