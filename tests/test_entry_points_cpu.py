@@ -1,0 +1,30 @@
+"""Every training entry script (the reference's file layout) starts, trains a few steps on the CPU and exits
+cleanly as a single process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ("--dataset synthetic --synthetic_tokens 65536 --vocab_size 256 --block_size 32 --n_embd 64 --n_layer 2 "
+          "--n_head 4 --up_dim 96 --attn mha --pos_emb learn --non_linearity gelu --batch_size 2 "
+          "--total_batch_size_str 2*32*2 --max_iters 3").split()
+SCRIPTS = ["single-gpu/train.py", "multi-gpu/ddp/train.py", "multi-gpu/ddp/kaggle-ddp.py", "multi-gpu/fsdp/train.py",
+           "multi-gpu/fsdp/kaggle-fsdp.py", "multi-gpu/zero1,2/train_zero1.py", "multi-gpu/zero1,2/train_zero2.py",
+           "multi-gpu/zero1,2/kaggle-zero1.py", "multi-gpu/zero1,2/kaggle-zero2.py", "multi-gpu/ep/train_ep.py",
+           "multi-gpu/ep/train_ep_fsdp.py"]
+
+
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_entry_script_trains(script, tmp_path):
+    extra = "--moe --n_exp 4 --n_shared 0 --n_act 2".split() if "/ep/" in script else []
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    cmd = [sys.executable, os.path.join(ROOT, script), *COMMON, *extra, "--data_dir", str(tmp_path / "data"),
+           "--file_name", str(tmp_path / "out")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step: 3 ")]
+    assert len(steps) == 1 and "train loss" in steps[0], r.stdout[-1500:]
