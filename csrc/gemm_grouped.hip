@@ -195,14 +195,24 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_wgrad_kernel(GroupedWgrad
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  char* ya = smem;
-  char* xa = smem + SUB;
-  for (long long t = t0; t < t1; ++t) {
+  // two LDS stages of (dY sub-tile, X sub-tile); the transfer of stage t+1 (LDS-DMA issued from assembly, so
+  // the compiler does not drain it before the next LDS read) overlaps the MFMAs of stage t
+  const unsigned lds0 = (unsigned)(size_t)(dma_lptr_t)smem;
+  auto issue = [&](long long t, int stage) {
     const long long m = start + t * 64;
-    __syncthreads();
-    dma_rows64x128(p.a + m * p.lda + n0, p.lda, p.N - n0, ya, wave, lane);
-    dma_rows64x128(p.b + m * p.ldb + k0, p.ldb, p.K - k0, xa, wave, lane);
-    __syncthreads();
+    const unsigned base = lds0 + stage * 2 * SUB;
+    dma_rows64x128_asm(p.a + m * p.lda + n0, p.lda, p.N - n0, base, wave, lane);
+    dma_rows64x128_asm(p.b + m * p.ldb + k0, p.ldb, p.K - k0, base + SUB, wave, lane);
+  };
+  if (t0 < t1) issue(t0, 0);
+  for (long long t = t0; t < t1; ++t) {
+    const int stage = (int)((t - t0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < t1) issue(t + 1, stage ^ 1);
+    const char* ya = smem + stage * 2 * SUB;
+    const char* xa = ya + SUB;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bfrag a[2], b[2];
@@ -258,7 +268,12 @@ void gemm_grouped_wgrad(const void* a, long long lda, const void* b, long long l
   p.splits = splits;
   if (splits > 1) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)ngroups * N * K, st);
   const dim3 grid(tiles * splits, ngroups), block(256);
-  hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, grid, block, (size_t)(2 * 64 * 128 * 2), st, p);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_grouped_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, grid, block, (size_t)(4 * 64 * 128 * 2), st, p);
 }
 
 // ------------------------------------------------------------------------------------------
