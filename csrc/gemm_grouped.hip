@@ -111,17 +111,26 @@ __global__ __launch_bounds__(256, 4) void gemm_grouped_kernel(GroupedArgs p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
     }
   }
+  // Epilogue through LDS: the accumulators hold one column per lane (2-byte stores, 64 contiguous bytes
+  // per half-wave); staged as a [128][128] bf16 image they leave as whole rows, 16 bytes per lane.
+  __syncthreads();   // every wave is done reading the operand tiles
+  bf16_t* ct = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = n0 + 64 * wn + 32 * j + r;
+      const int col = 64 * wn + 32 * j + r;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = m0 + 64 * wm + 32 * i + acc_row(q, hh);
-        if (row < p.rows && col < p.N) p.c[(long long)row * p.ldc + col] = f32_to_bf16(acc[i][j][q]);
-      }
+      for (int q = 0; q < 16; ++q) ct[(64 * wm + 32 * i + acc_row(q, hh)) * 128 + col] = f32_to_bf16(acc[i][j][q]);
     }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int id = tid + 256 * pass, row = id >> 4, ch = id & 15;
+    if (m0 + row < p.rows && n0 + ch * 8 < p.N)   // N % 8 == 0 (host-checked): a chunk is inside or outside
+      *reinterpret_cast<u32x4*>(p.c + (long long)(m0 + row) * p.ldc + n0 + ch * 8) =
+          *reinterpret_cast<const u32x4*>(ct + row * 128 + ch * 8);
+  }
 }
 
 static int grouped_xcd() {
