@@ -103,7 +103,7 @@ class Trainconfig:
     data_dir: str = ""                # overrides ../data/<dataset>
     synthetic_tokens: int = 0         # >0: generate a synthetic uint16 token stream of that length
     seed: int = 1729
-    resume: str = ""                  # path of a resume checkpoint written with --save_interval
+    resume: str = ""                  # resume checkpoint written with --save_interval; "auto" = this run's own, if present
     save_interval: int = 0
     metrics_jsonl: str = ""
     profile: bool = False

@@ -86,6 +86,12 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
         kwargs = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
             kwargs["device_id"] = device
+        restart = int(os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") or 0)
+        if restart > 0:
+            # Relaunched by torchrun --max-restarts: the agent's key-value store still holds the dead
+            # attempt's transport addresses under the default keys; give this attempt its own namespace.
+            base, _, _ = next(dist.rendezvous("env://", rank, world, timeout=kwargs["timeout"]))
+            kwargs["store"] = dist.PrefixStore(f"dpa_attempt_{restart}", base)
         dist.init_process_group(**kwargs)
     return DistInfo(rank, local_rank, world, device, backend)
 

@@ -131,9 +131,18 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
     optimizer = engine.configure_optimizers(weight_decay=tc.weight_decay, learning_rate=tc.learning_rate, device=device)
 
     start_iter = 0
-    if tc.resume:
-        start_iter = load_resume(tc.resume, engine, (train_loader, val_loader), info.rank) + 1
-        say(f"resumed from {tc.resume} at iteration {start_iter}")
+    resume_path = tc.resume
+    if resume_path == "auto":
+        # restart-friendly: continue from this run's own periodic resume files if every rank has one
+        # (torchrun --max-restarts relaunches the same command line after a failure), else start fresh
+        cand = tc.file_name + "_resume"
+        have = torch.tensor([1.0 if os.path.exists(f"{cand}.rank{info.rank}") else 0.0], device=device)
+        comm.all_reduce(have, op=torch.distributed.ReduceOp.MIN)
+        resume_path = cand if have.item() > 0 else ""
+        say(f"--resume auto: {'found ' + cand if resume_path else 'no resume files, starting fresh'}")
+    if resume_path:
+        start_iter = load_resume(resume_path, engine, (train_loader, val_loader), info.rank) + 1
+        say(f"resumed from {resume_path} at iteration {start_iter}")
 
     # Launch-bound steps (few tokens per step) are replayed from one hipGraph, the role torch.compile
     # plays in the reference trainer (reference: single-gpu/train.py:262-266). "auto" turns it on for
@@ -156,7 +165,16 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
     x, y = train_loader.next_batch()
     last_loss = float("nan")
     tokens_per_s = 0.0
+    # Fault injection for restart drills: DPA_FAULT_AT_ITER=<n> makes the last rank die once at iteration n
+    # (a marker file keeps the relaunched job from dying again).
+    fault_at = int(os.environ.get("DPA_FAULT_AT_ITER", "-1"))
     for it in range(start_iter, tc.max_iters + 1):
+        if it == fault_at and info.rank == info.world_size - 1:
+            marker = tc.file_name + "_fault_injected"
+            if not os.path.exists(marker):
+                open(marker, "w").close()
+                print(f"[fault injection] rank {info.rank} exits at iteration {it}", flush=True)
+                os._exit(17)
         t0 = perf_counter()
         lr = get_lr(it, tc)
         for pg in optimizer.param_groups:

@@ -77,6 +77,14 @@ def test_resume_continues_identically(tmp_path):
     tc, mc = configs_from_args((base + f" --max_iters 6 --resume {tmp_path / 'b_resume'} --file_name {tmp_path / 'c'}").split())
     resumed = train(tc, mc, "single")
     assert resumed["losses"] == pytest.approx(full["losses"][5:], rel=1e-5)
+    # "--resume auto": the same command line picks up its own resume files when they exist ...
+    tc, mc = configs_from_args((base + f" --max_iters 6 --save_interval 4 --resume auto --file_name {tmp_path / 'b'}").split())
+    again = train(tc, mc, "single")
+    assert again["losses"] == pytest.approx(full["losses"][5:], rel=1e-5)
+    # ... and starts from scratch when there are none
+    tc, mc = configs_from_args((base + f" --max_iters 6 --resume auto --file_name {tmp_path / 'fresh'}").split())
+    fresh = train(tc, mc, "single")
+    assert fresh["losses"] == pytest.approx(full["losses"], rel=1e-5)
 
 
 def test_synthetic_data_is_rebuilt_for_another_vocabulary(tmp_path):
