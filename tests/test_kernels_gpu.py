@@ -727,3 +727,20 @@ def test_fused_sampler_follows_the_softmax_distribution(topk, temperature):
     a = ops.sample_fused(logits, temperature, topk, seed)
     assert torch.equal(a, ops.sample_fused(logits, temperature, topk, seed))
     assert not torch.equal(a, ops.sample_fused(logits, temperature, topk, seed + 1))
+
+
+def test_kv_append_writes_one_row_at_the_device_position():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    B, S, H, hs = 3, 32, 2, 64
+    kc = torch.zeros(B, S, H, hs, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    qkv = torch.randn(B, 1, (4 + 2 * H) * hs, device=DEV, dtype=torch.bfloat16)     # rows are slices of a fused projection
+    _, k, v = ops.split_qkv(qkv, 4, H)
+    pos = torch.tensor([5], dtype=torch.int64, device=DEV)
+    ops.kv_append(kc, vc, k, v, pos)
+    assert torch.equal(kc[:, 5], k[:, 0]) and torch.equal(vc[:, 5], v[:, 0])
+    assert kc[:, :5].abs().sum() == 0 and kc[:, 6:].abs().sum() == 0
+    before = kc.clone()
+    ops.kv_append(kc, vc, k, v, torch.tensor([S], dtype=torch.int64, device=DEV))   # past the end: nothing is written
+    assert torch.equal(kc, before)
