@@ -154,6 +154,7 @@ class EPEngine(DDPEngine):
             g.drop_init()
             self._pending.append(0)
             self._launched.append(True)
+            self._enable_direct_grads()   # the base class marked its groups before this one existed
 
     def _pre_forward(self):
         super()._pre_forward()
