@@ -1,0 +1,214 @@
+// Stand-alone check + timing of csrc/gemm_nt.hip (no PyTorch): every epilogue against a plain fp32
+// reference kernel on random operands, then TFLOP/s on the GPT-2 layer shapes.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Icsrc benchmarks/gemm_nt_driver.hip csrc/gemm_nt.hip -o benchmarks/gemm_nt_driver.bin
+//   ./benchmarks/gemm_nt_driver.bin [check|bench|all]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "kernels.h"
+
+#define CK(x)                                                                        \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+      exit(2);                                                                       \
+    }                                                                                \
+  } while (0)
+
+typedef unsigned short bf16;
+
+static inline bf16 f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u = (u + 0x7fff + ((u >> 16) & 1)) >> 16;
+  return (bf16)u;
+}
+
+__device__ inline float bf2f(bf16 v) { return __uint_as_float(((unsigned)v) << 16); }
+
+__global__ void fill_kernel(bf16* p, long long n, unsigned seed, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    const float f = ((h & 0xffffff) / 8388608.0f - 1.0f) * scale;
+    __bf16 b = (__bf16)f;
+    p[i] = __builtin_bit_cast(bf16, b);
+  }
+}
+
+// fp32 reference of one epilogue: out[m][n] (fp32), aux[m][n] (fp32, GELU' for epi 1)
+__global__ void ref_kernel(const bf16* a, const bf16* b, const bf16* bias, const bf16* aux_in, float* out, float* aux,
+                           int M, int N, int K, long long lda, long long ldb, long long ld_aux, int epi, int row_step) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y * row_step;
+  if (n >= N || m >= M) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += bf2f(a[(long long)m * lda + k]) * bf2f(b[(long long)n * ldb + k]);
+  if (bias) s += bf2f(bias[n]);
+  const long long o = (long long)blockIdx.y * N + n;
+  if (epi == 1) {
+    const float phi = 0.5f * (1.f + erff(s * 0.70710678f));
+    out[o] = s * phi;
+    aux[o] = phi + s * 0.3989422804f * expf(-0.5f * s * s);
+  } else if (epi == 2) {
+    out[o] = s * bf2f(aux_in[(long long)m * ld_aux + n]);
+  } else if (epi == 3) {
+    out[o] = s + bf2f(aux_in[(long long)m * ld_aux + n]);
+  } else {
+    out[o] = s;
+  }
+}
+
+static int g_cus = 256;
+
+struct Bufs {
+  bf16 *a, *b, *c, *bias, *aux;
+  long long na, nb, nc;
+};
+
+static double run_case(int M, int N, int K, int epi, bool bias, bool check, int iters) {
+  bf16 *a, *b, *c, *bv, *aux;
+  const long long na = (long long)M * K, nb = (long long)N * K, nc = (long long)M * N;
+  CK(hipMalloc(&a, na * 2));
+  CK(hipMalloc(&b, nb * 2));
+  CK(hipMalloc(&c, nc * 2));
+  CK(hipMalloc(&aux, nc * 2));
+  CK(hipMalloc(&bv, (long long)N * 2));
+  fill_kernel<<<2048, 256>>>(a, na, 1u, 1.0f);
+  fill_kernel<<<2048, 256>>>(b, nb, 2u, 0.05f);
+  fill_kernel<<<64, 256>>>(bv, N, 3u, 0.5f);
+  fill_kernel<<<2048, 256>>>(aux, nc, 4u, 1.0f);
+  CK(hipMemset(c, 0xff, nc * 2));
+  dpa::GemmNtArgs g{};
+  g.a = a; g.b = b; g.c = c; g.bias = bias ? bv : nullptr;
+  g.aux_out = aux; g.aux_in = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ld_aux = N;
+  if (!dpa::gemm_nt_ok(M, N, K, K, K, N, N, bias)) {
+    printf("shape M=%d N=%d K=%d not supported\n", M, N, K);
+    return -1;
+  }
+  double worst = 0;
+  if (check) {
+    // reference rows: every row_step-th row
+    const int row_step = M > 4096 ? 37 : 1;
+    const int nrows = (M + row_step - 1) / row_step;
+    float *ro, *ra;
+    CK(hipMalloc(&ro, (long long)nrows * N * 4));
+    CK(hipMalloc(&ra, (long long)nrows * N * 4));
+    ref_kernel<<<dim3((N + 127) / 128, nrows), 128>>>(a, b, bias ? bv : nullptr, aux, ro, ra, M, N, K, K, K, N, epi, row_step);
+    CK(hipDeviceSynchronize());
+    dpa::gemm_nt(g, epi, g_cus, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<float> hro((size_t)nrows * N), hra((size_t)nrows * N);
+    std::vector<bf16> hc((size_t)nc), hx;
+    CK(hipMemcpy(hro.data(), ro, hro.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hra.data(), ra, hra.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hc.data(), c, nc * 2, hipMemcpyDeviceToHost));
+    if (epi == 1) {
+      hx.resize(nc);
+      CK(hipMemcpy(hx.data(), aux, nc * 2, hipMemcpyDeviceToHost));
+    }
+    long long bad = 0;
+    for (int r = 0; r < nrows; ++r) {
+      const long long m = (long long)r * row_step;
+      for (int n = 0; n < N; ++n) {
+        unsigned u = ((unsigned)hc[m * N + n]) << 16;
+        float got;
+        memcpy(&got, &u, 4);
+        const float want = hro[(size_t)r * N + n];
+        double err = fabs(got - want) / (fabs(want) + 0.05);
+        if (!(err < 2e-2)) {
+          if (bad < 5) printf("   mismatch c[%lld][%d] got %g want %g\n", m, n, got, want);
+          ++bad;
+        }
+        if (err > worst) worst = err;
+        if (epi == 1) {
+          unsigned u2 = ((unsigned)hx[m * N + n]) << 16;
+          float g2;
+          memcpy(&g2, &u2, 4);
+          const float w2 = hra[(size_t)r * N + n];
+          double e2 = fabs(g2 - w2) / (fabs(w2) + 0.05);
+          if (!(e2 < 2e-2)) {
+            if (bad < 5) printf("   mismatch aux[%lld][%d] got %g want %g\n", m, n, g2, w2);
+            ++bad;
+          }
+          if (e2 > worst) worst = e2;
+        }
+      }
+    }
+    printf("check M=%d N=%d K=%d epi=%d bias=%d: worst rel err %.3e, %lld bad of %lld  %s\n", M, N, K, epi, (int)bias,
+           worst, bad, (long long)nrows * N, bad ? "FAIL" : "ok");
+    fflush(stdout);
+    CK(hipFree(ro));
+    CK(hipFree(ra));
+    if (bad) exit(1);
+  }
+  double tf = 0;
+  if (iters > 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) dpa::gemm_nt(g, epi, g_cus, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < iters; ++i) {
+      CK(hipEventRecord(e0, 0));
+      dpa::gemm_nt(g, epi, g_cus, 0);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const float med = ts[ts.size() / 2];
+    tf = 2.0 * M * N * K / (med * 1e-3) / 1e12;
+    printf("bench M=%d N=%d K=%d epi=%d bias=%d: median %.1f us (min %.1f)  %.1f TF\n", M, N, K, epi, (int)bias,
+           med * 1e3, ts[0] * 1e3, tf);
+    fflush(stdout);
+  }
+  CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(c)); CK(hipFree(bv)); CK(hipFree(aux));
+  return tf;
+}
+
+int main(int argc, char** argv) {
+  const char* mode = argc > 1 ? argv[1] : "all";
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  g_cus = prop.multiProcessorCount;
+  printf("device %s, %d CUs\n", prop.name, g_cus);
+  if (!strcmp(mode, "check") || !strcmp(mode, "all")) {
+    run_case(256, 256, 128, 0, false, true, 0);
+    run_case(512, 512, 192, 0, false, true, 0);
+    run_case(1000, 752, 192, 0, true, true, 0);      // row and column tails
+    run_case(3000, 1040, 320, 0, false, true, 0);    // several tiles per workgroup? (no: fewer tiles than CUs)
+    run_case(40000, 2304, 768, 0, true, true, 0);    // persistent path: many tiles per workgroup, row tail
+    run_case(2048, 768, 256, 1, false, true, 0);
+    run_case(33000, 3072, 768, 1, false, true, 0);
+    run_case(2048, 768, 256, 2, true, true, 0);
+    run_case(33000, 3072, 768, 2, false, true, 0);
+    run_case(2100, 768, 256, 3, true, true, 0);
+    run_case(8192, 50304, 768, 0, false, true, 0);   // lm_head chunk: column tail, tiles_n = 197
+  }
+  if (!strcmp(mode, "bench") || !strcmp(mode, "all")) {
+    const int M = 65536;
+    run_case(M, 2304, 768, 0, true, false, 20);
+    run_case(M, 768, 768, 0, true, false, 20);
+    run_case(M, 3072, 768, 0, false, false, 20);
+    run_case(M, 768, 3072, 0, false, false, 20);
+    run_case(M, 3072, 768, 1, false, false, 20);
+    run_case(M, 3072, 768, 2, false, false, 20);
+    run_case(8192, 50304, 768, 0, false, false, 10);
+    run_case(8192, 768, 50304, 0, false, false, 10);
+    run_case(8192, 8192, 8192, 0, false, false, 10);
+    run_case(4096, 4096, 4096, 0, false, false, 20);
+  }
+  return 0;
+}

@@ -1,0 +1,513 @@
+// NT GEMM with fused epilogues for gfx950:   C[M, N] = epi( A[M, K] * B[N, K]^T )   (bf16 in, fp32
+// accumulate, bf16 out). Both operands are contraction-contiguous, which is the layout of every
+// forward product of a Linear layer (x * W^T) and, with the weight transposed once per optimizer
+// step, of every input-gradient product (dy * (W^T)^T) as well.
+//
+// Structure (one persistent 512-thread workgroup per CU, 256 x 256 output tile, 64-deep K-tiles):
+//  * 8 waves as 2 (M) x 4 (N), each owning 128 x 64 of the tile in 32 accumulators of
+//    v_mfma_f32_16x16x32_bf16. The product is formed transposed (the B rows are the MFMA's row
+//    operand), so a lane ends up with 16 CONSECUTIVE output columns of one output row and stores
+//    them as two 16-byte pieces; a quad of lanes writes one whole 128-byte line. No LDS transpose.
+//  * The two wave groups (rows 0-127 / 128-255) run the same program one barrier apart: while one
+//    group's 16 MFMAs of a phase occupy the matrix pipe of a SIMD, its partner on that SIMD issues
+//    the LDS reads and LDS-DMA of its own next phase ("ping-pong").
+//  * Operand tiles travel global -> LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane, issued
+//    from inline assembly and retired with counted s_waitcnt vmcnt, never vmcnt(0)); out-of-range rows
+//    read as zeros through the buffer descriptor's range check. A K-tile is four 16 KiB units
+//    (A rows 0-63 / 64-127 of both wave groups, B columns 0-31 / 32-63 of all four wave columns),
+//    two copies of each: one unit is refilled per phase, four phases (about a microsecond) ahead of
+//    its first read. The refill stream runs on across output tiles, so the first K-tiles of the next
+//    output tile land while this tile's epilogue runs.
+//  * LDS rows are 128 bytes (64 k); 16-byte chunk c of row r sits at chunk slot c ^ ((r >> 1) & 7),
+//    applied on the global source address of the DMA and again on the ds_read_b128 address:
+//    conflict-free for the 16-row x 4-chunk fragment reads.
+//  * Epilogues on the accumulators: + bias (staged once in LDS as fp32); exact-erf GELU that also
+//    emits GELU'(x) for the backward pass; x auxiliary tensor (the dGELU of the backward pass);
+//    + auxiliary tensor (residual).
+//
+// Replaces the GEMMs that nn.Linear issues implicitly in the reference
+// (reference: single-gpu/model.py:112-114,153,373-374,388-398,559).
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+
+constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
+constexpr int kCopy = 4 * kUnit;        // a K-tile: Am0, Am1, Bn0, Bn1
+constexpr int kBiasLds = 2 * kCopy;     // fp32 bias staged behind the two copies
+constexpr int kMaxBiasN = 8192;
+constexpr int kLds = kBiasLds + kMaxBiasN * 4;   // 160 KiB
+
+__device__ __forceinline__ f32x4 mfma16(bfrag8 a, bfrag8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from rs[voff] to LDS [lds_addr, lds_addr + 1024).
+__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, rsrc_t rs) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voff), "s"(rs)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Exact-erf GELU and its derivative. erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
+// Phi(-|x|) = 0.5 * t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2).
+__device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678f, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950409f));
+  float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = fmaf(poly, t, 0.5f * 1.421413741f);
+  poly = fmaf(poly, t, 0.5f * -0.284496736f);
+  poly = fmaf(poly, t, 0.5f * 0.254829592f);
+  const float h = poly * t * e;
+  const float phi = x >= 0.f ? 1.0f - h : h;
+  act = x * phi;
+  dact = fmaf(x * e, 0.3989422804f, phi);
+}
+
+struct TileCoord {
+  int m0, n0;
+};
+
+}  // namespace
+
+// Tile walk. Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the m-tiles are
+// split into 8 contiguous ranges, one per XCD label (blockIdx % 8), and inside a range the tiles that
+// run at the same time form blocks of 4 m-tiles x all n-tiles, so that concurrent workgroups of an
+// XCD share A and B panels through that L2. Any (blockIdx, iteration) -> tile bijection is correct;
+// this one is for locality.
+struct GemmWalk {
+  int tiles_m, tiles_n, nwg;
+  __device__ __forceinline__ bool xcd_mode() const { return tiles_m >= 8 && (nwg & 7) == 0; }
+  __device__ __forceinline__ int count(int wg) const {
+    if (!xcd_mode()) {
+      const int total = tiles_m * tiles_n;
+      return wg < total ? (total - wg + nwg - 1) / nwg : 0;
+    }
+    const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
+    const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
+    const int total = (hi - lo) * tiles_n;
+    return slot < total ? (total - slot + per - 1) / per : 0;
+  }
+  __device__ __forceinline__ TileCoord at(int wg, int it) const {
+    TileCoord t;
+    if (!xcd_mode()) {
+      const int s = wg + it * nwg;
+      t.m0 = (s % tiles_m) * 256;
+      t.n0 = (s / tiles_m) * 256;
+      return t;
+    }
+    const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
+    const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
+    const int s = slot + it * per;
+    const int gsz = 4 * tiles_n;
+    const int nfull = (hi - lo) / 4;
+    int g = s / gsz, r = s % gsz, gm = 4;
+    if (g >= nfull) {
+      g = nfull;
+      r = s - nfull * gsz;
+      gm = (hi - lo) - 4 * nfull;
+    }
+    t.n0 = (r / gm) * 256;
+    t.m0 = (lo + 4 * g + r % gm) * 256;
+    return t;
+  }
+};
+
+template <int EPI, bool BIAS>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int nk = p.K / 64;
+
+  const rsrc_t rsA = make_rsrc(p.a, p.a_bytes);
+  const rsrc_t rsB = make_rsrc(p.b, p.b_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+
+  if (BIAS) {
+    float* sb = reinterpret_cast<float*>(smem + kBiasLds);
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+    for (int i = tid; i < p.N; i += 512) sb[i] = bf16_to_f32(bias[i]);
+    __syncthreads();
+  }
+
+  // ---- LDS-DMA source offsets of this lane (bytes inside the 256-row A / B panel of a tile) -------
+  // Piece pc = 2 * wave + pp of a unit covers unit rows 8 pc .. 8 pc + 7; lane l -> row 8 pc + (l >> 3),
+  // chunk slot l & 7, which must receive logical chunk (l & 7) ^ ((row >> 1) & 7).
+  unsigned voffA0, voffA1, voffB0, voffB1, pieceLds0, pieceLds1;
+  {
+    auto piece = [&](int pp, unsigned& va, unsigned& vb, unsigned& pl) {
+      const int pc = 2 * wave + pp;
+      const int rho = 8 * pc + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+      // A unit Am{mh}: unit row rho <-> tile row 128 (rho >> 6) + 64 mh + (rho & 63)
+      const int rowA = 128 * (rho >> 6) + (rho & 63);
+      va = (unsigned)rowA * (unsigned)p.lda * 2u + chunk * 16;
+      // B unit Bn{nh}: unit row rho = 32 wc + 16 nt + i <-> tile column 64 wc + 16 (i >> 2) + 4 (2 nh + nt) + (i & 3)
+      const int i = rho & 15, nt = (rho >> 4) & 1, wcs = rho >> 5;
+      const int colB = 64 * wcs + 16 * (i >> 2) + 4 * nt + (i & 3);
+      vb = (unsigned)colB * (unsigned)p.ldb * 2u + chunk * 16;
+      pl = lds0 + pc * 1024;
+    };
+    piece(0, voffA0, voffB0, pieceLds0);
+    piece(1, voffA1, voffB1, pieceLds1);
+    // opaque from here on: keeps every issue at one scalar base + one v_add per piece
+    asm volatile("" : "+v"(voffA0), "+v"(voffA1), "+v"(voffB0), "+v"(voffB1));
+    pieceLds0 = __builtin_amdgcn_readfirstlane(pieceLds0);
+    pieceLds1 = __builtin_amdgcn_readfirstlane(pieceLds1);
+  }
+  const unsigned aStepMh = 64u * (unsigned)p.lda * 2u;   // Am1 rows = Am0 rows + 64
+  const unsigned bStepNh = 8u * (unsigned)p.ldb * 2u;    // Bn1 columns = Bn0 columns + 8
+
+  // ---- fragment read offsets (bytes inside a unit) -------------------------------------------------
+  unsigned aoff0, aoff1, boff0, boff1;
+  {
+    const int rhoA = 64 * wr + l15, rhoB = 32 * wc + l15;
+    aoff0 = rhoA * 128 + (((0 + q) ^ ((rhoA >> 1) & 7)) << 4);
+    aoff1 = rhoA * 128 + (((4 + q) ^ ((rhoA >> 1) & 7)) << 4);
+    boff0 = rhoB * 128 + (((0 + q) ^ ((rhoB >> 1) & 7)) << 4);
+    boff1 = rhoB * 128 + (((4 + q) ^ ((rhoB >> 1) & 7)) << 4);
+  }
+
+  GemmWalk walk{p.tiles_m, p.tiles_n, (int)gridDim.x};
+  const int wg = blockIdx.x;
+  const int ntiles = walk.count(wg);
+  if (ntiles == 0) return;
+
+  // ---- refill stream ---------------------------------------------------------------------------
+  // Units are issued in the fixed order Am0, Bn0 | Bn1, Am1 of consecutive K-tiles, running on into
+  // the next output tile; past the last tile the offsets point outside the buffers (zeros, never read).
+  int cur_m0, cur_n0, nxt_m0, nxt_n0;
+  {
+    const TileCoord t0 = walk.at(wg, 0);
+    cur_m0 = t0.m0;
+    cur_n0 = t0.n0;
+    nxt_m0 = cur_m0;
+    nxt_n0 = cur_n0;
+  }
+  bool have_nxt = ntiles > 1;
+  if (have_nxt) {
+    const TileCoord t1 = walk.at(wg, 1);
+    nxt_m0 = t1.m0;
+    nxt_n0 = t1.n0;
+  }
+  // a dead refill (past the last tile) is aimed at offsets >= 2 GiB, beyond every buffer: it reads zeros
+  const unsigned kOob = 0x80000000u;
+
+  // IS_A / HALF are compile-time tags (std::integral_constant): unit Am{HALF} or Bn{HALF} of K-tile kk
+  // (kk may run into the next output tile) goes to LDS copy `copy`.
+  auto issue = [&](auto is_a_tag, auto half_tag, int kk, int copy) {
+    constexpr bool IS_A = decltype(is_a_tag)::value;
+    constexpr int HALF = decltype(half_tag)::value;
+    const bool over = kk >= nk;
+    const unsigned k = (unsigned)(over ? kk - nk : kk) * 128u;
+    unsigned base;
+    if (IS_A) base = (unsigned)(over ? nxt_m0 : cur_m0) * (unsigned)p.lda * 2u + (HALF ? aStepMh : 0u) + k;
+    else base = (unsigned)(over ? nxt_n0 : cur_n0) * (unsigned)p.ldb * 2u + (HALF ? bStepNh : 0u) + k;
+    if (over && !have_nxt) base = kOob;
+    const unsigned ldsu = copy * kCopy + ((IS_A ? 0 : 2) + HALF) * kUnit;
+    const unsigned v0 = base + (IS_A ? voffA0 : voffB0);
+    const unsigned v1 = base + (IS_A ? voffA1 : voffB1);
+    dma16(pieceLds0 + ldsu, v0, IS_A ? rsA : rsB);
+    dma16(pieceLds1 + ldsu, v1, IS_A ? rsA : rsB);
+  };
+  using TA = std::true_type;
+  using TB = std::false_type;
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+
+  f32x4 acc[2][4][4];
+  bfrag8 af[4][2], bf0[2][2], bf1[2][2];
+
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto read_a = [&](int copy, int mh) {
+    const char* u = smem + copy * kCopy + mh * kUnit;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[mt][ks] = *reinterpret_cast<const bfrag8*>(u + (ks ? aoff1 : aoff0) + mt * 2048);
+  };
+  auto read_b = [&](int copy, int nh, bfrag8 (&bf)[2][2]) {
+    const char* u = smem + copy * kCopy + (2 + nh) * kUnit;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        bf[nt][ks] = *reinterpret_cast<const bfrag8*>(u + (ks ? boff1 : boff0) + nt * 2048);
+  };
+  auto quadrant = [&](int mh, int nh, const bfrag8 (&bf)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mh][mt][2 * nh + nt] = mfma16(bf[nt][ks], af[mt][ks], acc[mh][mt][2 * nh + nt]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // One K-tile = four phases; W = vector-memory operations allowed to stay in flight at each wait
+  // (8 = the four most recent units; + the epilogue's stores while they are younger than the unit
+  // being waited for).
+  auto ktile = [&](int kt, int copy, auto wtag) {
+    constexpr int W = decltype(wtag)::value;
+    // phase 0: quadrant (rows 0-63, columns 0-31)
+    read_a(copy, 0);
+    read_b(copy, 0, bf0);
+    issue(TB{}, H1{}, kt + 1, copy ^ 1);
+    wait_vm<W>();
+    barrier();
+    quadrant(0, 0, bf0);
+    barrier();
+    // phase 1: (rows 0-63, columns 32-63)
+    read_b(copy, 1, bf1);
+    issue(TA{}, H1{}, kt + 1, copy ^ 1);
+    wait_vm<W>();
+    barrier();
+    quadrant(0, 1, bf1);
+    barrier();
+    // phase 2: (rows 64-127, columns 32-63)
+    read_a(copy, 1);
+    issue(TA{}, H0{}, kt + 2, copy);
+    wait_vm<W>();
+    barrier();
+    quadrant(1, 1, bf1);
+    barrier();
+    // phase 3: (rows 64-127, columns 0-31), operands already in registers
+    issue(TB{}, H0{}, kt + 2, copy);
+    wait_vm<W>();
+    barrier();
+    quadrant(1, 0, bf0);
+    barrier();
+  };
+
+  // ---- prologue: the first six units of the first tile ----------------------------------------------
+  issue(TA{}, H0{}, 0, 0);
+  issue(TB{}, H0{}, 0, 0);
+  issue(TB{}, H1{}, 0, 0);
+  issue(TA{}, H1{}, 0, 0);
+  issue(TA{}, H0{}, 1, 1);
+  issue(TB{}, H0{}, 1, 1);
+  wait_vm<8>();
+  barrier();
+  if (wr == 1) barrier();   // the second wave group runs one barrier behind the first
+
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(p.aux_out, 0, (int)p.aux_bytes, 0x00020000);
+  constexpr int kStores = (EPI == kEpiGelu) ? 32 : 16;   // epilogue stores per wave and tile
+
+  int copy = 0;
+  for (int it = 0; it < ntiles; ++it) {
+    zero_acc();
+    if (it == 0) ktile(0, copy, std::integral_constant<int, 8>{});
+    else ktile(0, copy, std::integral_constant<int, 8 + kStores>{});
+    copy ^= 1;
+    for (int kt = 1; kt < nk; ++kt) {
+      ktile(kt, copy, std::integral_constant<int, 8>{});
+      copy ^= 1;
+    }
+
+    // ---- epilogue (no barriers, no LDS-DMA: only stores, counted in the next tile's first waits) ----
+    {
+      const int colq = cur_n0 + 64 * wc + 16 * q;          // first of this lane's 16 columns
+      const bool col_ok = colq < p.N;
+      float bv[16];
+      if (BIAS) {
+        const float* sb = reinterpret_cast<const float*>(smem + kBiasLds);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bv[j] = col_ok ? sb[colq + j] : 0.f;
+      }
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int row = cur_m0 + 128 * wr + 64 * mh + 16 * mt + l15;
+          const bool ok = col_ok && row < p.M;
+          float v[16];
+#pragma unroll
+          for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * T + e] = acc[mh][mt][T][e] + (BIAS ? bv[4 * T + e] : 0.f);
+          const unsigned coff = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)colq) * 2u : 0x80000000u;
+          if (EPI == kEpiMul || EPI == kEpiAdd) {
+            const unsigned xoff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0u;
+            const u32x4* xp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux_in) + xoff);
+            const u32x4 x0 = xp[0], x1 = xp[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a0 = lo_bf16(x0[j]), a1 = hi_bf16(x0[j]), a2 = lo_bf16(x1[j]), a3 = hi_bf16(x1[j]);
+              if (EPI == kEpiMul) {
+                v[2 * j] *= a0; v[2 * j + 1] *= a1; v[8 + 2 * j] *= a2; v[8 + 2 * j + 1] *= a3;
+              } else {
+                v[2 * j] += a0; v[2 * j + 1] += a1; v[8 + 2 * j] += a2; v[8 + 2 * j + 1] += a3;
+              }
+            }
+          }
+          u32x4 o0, o1;
+          if (EPI == kEpiGelu) {
+            u32x4 g0, g1;
+            float a[16], d[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gelu_and_grad(v[j], a[j], d[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              o0[j] = pack_bf16x2(a[2 * j], a[2 * j + 1]);
+              o1[j] = pack_bf16x2(a[8 + 2 * j], a[8 + 2 * j + 1]);
+              g0[j] = pack_bf16x2(d[2 * j], d[2 * j + 1]);
+              g1[j] = pack_bf16x2(d[8 + 2 * j], d[8 + 2 * j + 1]);
+            }
+            const unsigned goff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(g0, rsG, goff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(g1, rsG, goff + 16, 0, 0);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              o0[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+              o1[j] = pack_bf16x2(v[8 + 2 * j], v[8 + 2 * j + 1]);
+            }
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(o0, rsC, coff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o1, rsC, coff + 16, 0, 0);
+        }
+    }
+    cur_m0 = nxt_m0;
+    cur_n0 = nxt_n0;
+    have_nxt = it + 2 < ntiles;
+    if (have_nxt) {
+      const TileCoord t2 = walk.at(wg, it + 2);
+      nxt_m0 = t2.m0;
+      nxt_n0 = t2.n0;
+    }
+  }
+  if (wr == 0) barrier();   // pairs with the extra barrier the second wave group started with
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (zero-fill) LDS-DMA before the LDS is released
+}
+
+// out[C, R] = in[R, C]^T through a padded 64 x 64 LDS tile (16-byte global accesses both ways).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int R, int C) {
+  __shared__ bf16_t tile[64][72];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i, r = id >> 3, ch = id & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < R && c0 + ch * 8 < C) v = *reinterpret_cast<const u32x4*>(in + (long long)(r0 + r) * C + c0 + ch * 8);
+    *reinterpret_cast<u32x4*>(&tile[r][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i, c = id >> 3, ch = id & 7;
+    if (c0 + c < C && r0 + ch * 8 < R) {
+      bf16_t t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = tile[ch * 8 + j][c];
+      u32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (unsigned)t[2 * j] | ((unsigned)t[2 * j + 1] << 16);
+      *reinterpret_cast<u32x4*>(out + (long long)(c0 + c) * R + r0 + ch * 8) = v;
+    }
+  }
+}
+
+void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st) {
+  if (R == 0 || C == 0) return;
+  const dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, R, C);
+}
+
+bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
+                bool has_bias) {
+  const long long lim = 0x80000000ll;   // offsets at or above 2 GiB are the "outside every buffer" range
+  if (M < 1 || N < 16 || K < 128 || K % 64 != 0 || N % 16 != 0) return false;
+  if (lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ld_aux % 8 != 0) return false;
+  if (lda < K || ldb < K || ldc < N || (ld_aux != 0 && ld_aux < N)) return false;
+  if (M * lda * 2 >= lim || N * ldb * 2 >= lim || M * ldc * 2 >= lim || M * ld_aux * 2 >= lim) return false;
+  if (256 * lda * 2 >= (1ll << 30) || 256 * ldb * 2 >= (1ll << 30)) return false;
+  if (has_bias && N > kMaxBiasN) return false;
+  return true;
+}
+
+void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
+  if (a.M == 0 || a.N == 0) return;
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  a.a_bytes = (unsigned)(((long long)a.M - 1) * a.lda * 2 + (long long)a.K * 2);
+  a.b_bytes = (unsigned)(((long long)a.N - 1) * a.ldb * 2 + (long long)a.K * 2);
+  a.c_bytes = (unsigned)(((long long)a.M - 1) * a.ldc * 2 + (long long)a.N * 2);
+  a.aux_bytes = (unsigned)(((long long)a.M - 1) * a.ld_aux * 2 + (long long)a.N * 2);
+  const int total = a.tiles_m * a.tiles_n;
+  int grid = num_cus > 0 ? num_cus : 256;
+  grid &= ~7;
+  if (grid < 8) grid = 8;
+  if (a.tiles_m < 8 && grid > total) grid = total;
+  static bool attr = false;
+#define DPA_GNT_ALL(F)                                                                  \
+  F(kEpiNone, false) F(kEpiNone, true) F(kEpiGelu, false) F(kEpiGelu, true) F(kEpiMul, false) F(kEpiMul, true) \
+  F(kEpiAdd, false) F(kEpiAdd, true)
+  if (!attr) {
+#define DPA_GNT_ATTR(E, B) \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, B>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    DPA_GNT_ALL(DPA_GNT_ATTR)
+#undef DPA_GNT_ATTR
+    attr = true;
+  }
+  const bool bias = a.bias != nullptr;
+#define DPA_GNT_LAUNCH(E, B)                                                                              \
+  if (epi == E && bias == B) {                                                                            \
+    hipLaunchKernelGGL((gemm_nt_kernel<E, B>), dim3(grid), dim3(512), kLds, st, a);                       \
+    return;                                                                                               \
+  }
+  DPA_GNT_ALL(DPA_GNT_LAUNCH)
+#undef DPA_GNT_LAUNCH
+#undef DPA_GNT_ALL
+}
+
+}  // namespace dpa

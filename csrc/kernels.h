@@ -107,6 +107,32 @@ void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accu
 void wgrad_finish_many(const float* ws, const long long* dst_ptrs, int count, long long n, bool accumulate,
                        bool out_bf16, hipStream_t st);
 
+// ---- NT GEMM with fused epilogues (csrc/gemm_nt.hip) ------------------------------------------------
+// c[M, N] = epi(a[M, K] * b[N, K]^T [+ bias[N]]), bf16 operands and results, fp32 accumulation.
+//   kEpiNone : c = v
+//   kEpiGelu : c = GELU_erf(v), aux_out = GELU_erf'(v)      (aux_out [M, N], row stride ld_aux)
+//   kEpiMul  : c = v * aux_in                                (aux_in  [M, N], row stride ld_aux)
+//   kEpiAdd  : c = v + aux_in
+// K % 64 == 0, K >= 128, N % 16 == 0, rows 16-byte aligned, every tensor below 4 GB - 16 MB,
+// bias only for N <= 8192 (gemm_nt_ok checks all of it).
+enum { kEpiNone = 0, kEpiGelu = 1, kEpiMul = 2, kEpiAdd = 3 };
+struct GemmNtArgs {
+  const void *a, *b;
+  void* c;
+  const void* bias;     // [N] bf16 or nullptr
+  void* aux_out;
+  const void* aux_in;
+  int M, N, K;
+  long long lda, ldb, ldc, ld_aux;   // row strides in elements
+  unsigned a_bytes, b_bytes, c_bytes, aux_bytes;   // filled by gemm_nt()
+  int tiles_m, tiles_n;                            // filled by gemm_nt()
+};
+bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
+                bool has_bias);
+void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st);
+// out[C, R] = in[R, C]^T (bf16, R % 8 == 0 and C % 8 == 0, contiguous).
+void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
+
 // ---- Grouped GEMM (MoE experts) ----------------------------------------------------------------
 // c[rows, N] = a[rows, K] * W_g, one weight matrix per 128-row block (block_group[rb]; values outside
 // [0, ngroups) skip the block). w_is_kn = false: W_g is [N, K]; true: W_g is [K, N]. K % 64 == 0,
