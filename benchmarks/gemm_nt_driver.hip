@@ -197,6 +197,62 @@ int main(int argc, char** argv) {
     run_case(2100, 768, 256, 3, true, true, 0);
     run_case(8192, 50304, 768, 0, false, true, 0);   // lm_head chunk: column tail, tiles_n = 197
   }
+  if (!strcmp(mode, "variants")) {
+    const int M = 65536;
+    for (int v : {0, 1, 2, 3}) {
+      printf("---- variant %d (bit0: one barrier per phase, bit1: stores dropped)\n", v);
+      dpa::gemm_nt_set_variant(v);
+      if (v < 2) run_case(33000, 3072, 768, 1, false, true, 0);
+      run_case(M, 2304, 768, 0, true, false, 20);
+      run_case(M, 3072, 768, 0, false, false, 20);
+      run_case(M, 768, 3072, 0, false, false, 20);
+      run_case(M, 3072, 768, 1, false, false, 20);
+      run_case(M, 3072, 768, 2, false, false, 20);
+      run_case(4096, 4096, 4096, 0, false, false, 20);
+    }
+  }
+  if (!strcmp(mode, "prof")) {   // prof <variant> <N> <K> <epi>: a few launches of one shape for rocprofv3
+    dpa::gemm_nt_set_variant(argc > 2 ? atoi(argv[2]) : 0);
+    run_case(65536, argc > 3 ? atoi(argv[3]) : 3072, argc > 4 ? atoi(argv[4]) : 768, argc > 5 ? atoi(argv[5]) : 0, false, false, 5);
+  }
+  if (!strcmp(mode, "ablate")) {   // timing-only ablations (build with -DDPA_GEMM_ABLATE), stores dropped
+    for (int abl : {0, 1, 2, 3, 4, 8, 9, 10, 12}) {
+      printf("---- ablation %d (1 no DMA, 2 no reads, 4 no barriers, 8 no MFMA)\n", abl);
+      dpa::gemm_nt_set_variant(2 | (abl << 4));
+      run_case(65536, 3072, 768, 0, false, false, 10);
+      run_case(4096, 4096, 4096, 0, false, false, 10);
+    }
+  }
+  if (!strcmp(mode, "grid")) {   // store cost against the number of workgroups (per-CU or chip-wide limit?)
+    for (int cus : {256, 128, 64, 32}) {
+      g_cus = cus;
+      for (int v : {0, 2}) {
+        printf("---- %d workgroups, stores %s\n", cus, v ? "dropped" : "on");
+        dpa::gemm_nt_set_variant(v);
+        run_case(65536, 3072, 768, 0, false, false, 8);
+      }
+    }
+  }
+  if (!strcmp(mode, "quick")) {
+    const int M = 65536;
+    run_case(4000, 2304, 768, 1, true, true, 0);
+    run_case(M, 2304, 768, 0, true, false, 20);
+    run_case(M, 3072, 768, 0, false, false, 20);
+    run_case(M, 768, 3072, 0, false, false, 20);
+    run_case(M, 3072, 768, 1, false, false, 20);
+    run_case(M, 3072, 768, 2, false, false, 20);
+  }
+  if (!strcmp(mode, "skew")) {
+    const int M = 65536;
+    for (int ticks : {0, 200, 400, 600, 800}) {   // 100 MHz ticks per group step: 0 .. 8 us
+      printf("---- skew step %d ticks (%.1f us)\n", ticks, ticks / 100.0);
+      dpa::gemm_nt_set_variant(ticks << 8);
+      run_case(M, 2304, 768, 0, true, false, 20);
+      run_case(M, 3072, 768, 0, false, false, 20);
+      run_case(M, 3072, 768, 1, false, false, 20);
+      run_case(M, 3072, 768, 2, false, false, 20);
+    }
+  }
   if (!strcmp(mode, "bench") || !strcmp(mode, "all")) {
     const int M = 65536;
     run_case(M, 2304, 768, 0, true, false, 20);

@@ -787,7 +787,88 @@ void ws_to_many(const Tensor& ws, const Tensor& dst_ptrs, bool accumulate, bool 
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------
+// c[M, N] = epi(a[M, K] * b[N, K]^T + bias), see kernels.h. a may be a row-strided 2-D view; aux is the
+// second operand of the multiply / add epilogues. Returns (c, aux_out) with aux_out = GELU'(v) for the
+// GELU epilogue and an empty tensor otherwise.
+int gemm_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+bool gemm_nt_supported(const Tensor& a, const Tensor& b, const std::optional<Tensor>& bias,
+                       const std::optional<Tensor>& aux) {
+  if (!a.is_cuda() || !b.is_cuda() || a.dim() != 2 || b.dim() != 2) return false;
+  if (a.scalar_type() != at::kBFloat16 || b.scalar_type() != at::kBFloat16) return false;
+  if (a.stride(1) != 1 || b.stride(1) != 1 || a.size(1) != b.size(1)) return false;
+  if (reinterpret_cast<uintptr_t>(a.data_ptr()) % 16 || reinterpret_cast<uintptr_t>(b.data_ptr()) % 16) return false;
+  if (a.size(0) < 1) return false;
+  int64_t ld_aux = 0;
+  if (aux.has_value()) {
+    if (!aux->is_cuda() || aux->scalar_type() != at::kBFloat16 || aux->dim() != 2 || aux->stride(1) != 1 ||
+        aux->size(0) != a.size(0) || aux->size(1) != b.size(0) || reinterpret_cast<uintptr_t>(aux->data_ptr()) % 16)
+      return false;
+    ld_aux = aux->stride(0);
+  }
+  if (bias.has_value() && (!bias->is_cuda() || bias->scalar_type() != at::kBFloat16 || !bias->is_contiguous() ||
+                           bias->numel() != b.size(0)))
+    return false;
+  return dpa::gemm_nt_ok(a.size(0), b.size(0), a.size(1), a.stride(0), b.stride(0), b.size(0),
+                         ld_aux ? ld_aux : b.size(0), bias.has_value());
+}
+
+std::tuple<Tensor, std::optional<Tensor>> gemm_nt(const Tensor& a, const Tensor& b, const std::optional<Tensor>& bias, int64_t epi,
+                                   const std::optional<Tensor>& aux) {
+  TORCH_CHECK(epi >= 0 && epi <= 3, "gemm_nt: epilogue 0..3");
+  TORCH_CHECK((epi == dpa::kEpiMul || epi == dpa::kEpiAdd) == aux.has_value(),
+              "gemm_nt: the multiply / add epilogues (and only they) take an auxiliary operand");
+  TORCH_CHECK(gemm_nt_supported(a, b, bias, aux), "gemm_nt: unsupported operands (see gemm_nt_supported)");
+  const int64_t M = a.size(0), N = b.size(0), K = a.size(1);
+  Tensor c = at::empty({M, N}, a.options());
+  std::optional<Tensor> aux_out;
+  dpa::GemmNtArgs g{};
+  g.a = a.data_ptr();
+  g.b = b.data_ptr();
+  g.c = c.data_ptr();
+  g.bias = bias.has_value() ? bias->data_ptr() : nullptr;
+  g.M = (int)M;
+  g.N = (int)N;
+  g.K = (int)K;
+  g.lda = a.stride(0);
+  g.ldb = b.stride(0);
+  g.ldc = N;
+  g.ld_aux = N;
+  if (epi == dpa::kEpiGelu) {
+    aux_out = at::empty({M, N}, a.options());
+    g.aux_out = aux_out->data_ptr();
+  } else if (aux.has_value()) {
+    g.aux_in = aux->data_ptr();
+    g.ld_aux = aux->stride(0);
+  }
+  dpa::gemm_nt(g, (int)epi, gemm_cus(), cur_stream());
+  return {c, aux_out};
+}
+
+Tensor transpose_bf16(const Tensor& x) {
+  TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == at::kBFloat16 && x.is_contiguous() &&
+                  x.size(0) % 8 == 0 && x.size(1) % 8 == 0 && reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
+              "transpose_bf16: contiguous bf16 [R, C] with R, C multiples of 8");
+  Tensor out = at::empty({x.size(1), x.size(0)}, x.options());
+  dpa::transpose_bf16(x.data_ptr(), out.data_ptr(), (int)x.size(0), (int)x.size(1), cur_stream());
+  return out;
+}
+
 TORCH_LIBRARY(dpa, m) {
+  m.def("gemm_nt(Tensor a, Tensor b, Tensor? bias, int epi, Tensor? aux) -> (Tensor, Tensor?)");
+  m.def("gemm_nt_supported(Tensor a, Tensor b, Tensor? bias, Tensor? aux) -> bool");
+  m.def("gemm_nt_set_variant(int v) -> ()");
+  m.def("transpose_bf16(Tensor x) -> Tensor");
   m.def("ws_to_many(Tensor ws, Tensor dst_ptrs, bool accumulate, bool out_bf16) -> ()");
   m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
   m.def("wgrad2_direct(Tensor dy, Tensor x, Tensor(a!) dw_acc, Tensor(b!)? db_acc) -> ()");
@@ -838,10 +919,14 @@ TORCH_LIBRARY(dpa, m) {
 
 TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
   m.impl("wgrad2_set_stages", [](int64_t s) { dpa::wgrad2_set_stages((int)s); });
+  m.impl("gemm_nt_set_variant", [](int64_t v) { dpa::gemm_nt_set_variant((int)v); });
+  m.impl("gemm_nt_supported", gemm_nt_supported);
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("ws_to_many", ws_to_many);
+  m.impl("gemm_nt", gemm_nt);
+  m.impl("transpose_bf16", transpose_bf16);
   m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);
   m.impl("wgrad2_direct", wgrad2_direct);
   m.impl("moe_topk_gate", moe_topk_gate);

@@ -39,6 +39,10 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
 typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 
+#ifndef DPA_GEMM_STORE_AUX
+#define DPA_GEMM_STORE_AUX 2   // non-temporal: measured 4-6 % faster than the default policy on the K = 768 shapes
+#endif
+constexpr int kStoreAux = DPA_GEMM_STORE_AUX;   // cache policy bits of the epilogue stores (1 sc0, 2 nt, 16 sc1)
 constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
 constexpr int kCopy = 4 * kUnit;        // a K-tile: Am0, Am1, Bn0, Bn1
 constexpr int kBiasLds = 2 * kCopy;     // fp32 bias staged behind the two copies
@@ -103,6 +107,13 @@ struct TileCoord {
   int m0, n0;
 };
 
+// vmcnt immediates of the four phases of a K-tile, and whether phases 0 and 1 issue a unit refill
+template <int W0, int W1, int W2, int W3, bool ISSUE01>
+struct KtCfg {
+  static constexpr int kW0 = W0, kW1 = W1, kW2 = W2, kW3 = W3;
+  static constexpr bool kIssue01 = ISSUE01;
+};
+
 }  // namespace
 
 // Tile walk. Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the m-tiles are
@@ -148,7 +159,9 @@ struct GemmWalk {
   }
 };
 
-template <int EPI, bool BIAS>
+// ABL (timing-only ablations, results wrong): 1 = no LDS-DMA in the K-loop, 2 = no fragment reads, 4 = no
+// barriers, 8 = no MFMAs.
+template <int EPI, bool BIAS, int SYNC, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -206,6 +219,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     boff1 = rhoB * 128 + (((4 + q) ^ ((rhoB >> 1) & 7)) << 4);
   }
 
+  if (p.skew_ticks > 0) {   // benchmark aid: start the workgroups in four groups a quarter of a tile apart
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * p.skew_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   GemmWalk walk{p.tiles_m, p.tiles_n, (int)gridDim.x};
   const int wg = blockIdx.x;
   const int ntiles = walk.count(wg);
@@ -245,6 +263,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     const unsigned ldsu = copy * kCopy + ((IS_A ? 0 : 2) + HALF) * kUnit;
     const unsigned v0 = base + (IS_A ? voffA0 : voffB0);
     const unsigned v1 = base + (IS_A ? voffA1 : voffB1);
+    if (ABL & 1) {
+      asm volatile("" ::"v"(v0), "v"(v1), "s"(ldsu));
+      return;
+    }
     dma16(pieceLds0 + ldsu, v0, IS_A ? rsA : rsB);
     dma16(pieceLds1 + ldsu, v1, IS_A ? rsA : rsB);
   };
@@ -253,8 +275,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
 
+  // A lane holds columns colq .. colq + 15 of row row0 + l15 as two 16-byte halves. Lanes l15 and
+  // l15 ^ 8 trade one half each (DPP row rotate by 8), after which every store instruction writes 8
+  // whole 128-byte lines instead of 16 lines by half: lane l15 < 8 keeps its low half and gets the low
+  // half of row + 8, lane l15 >= 8 keeps its high half and gets the high half of row - 8.
+  auto store_rows16 = [&](__amdgpu_buffer_rsrc_t rs, u32x4 lo, u32x4 hi, int row0, int colq, unsigned ld, bool col_ok) {
+    const bool low = l15 < 8;
+    u32x4 recv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      recv[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(low ? hi[j] : lo[j]), 0x128, 0xf, 0xf, false);
+    const u32x4 st1 = low ? lo : recv, st2 = low ? recv : hi;
+    const int r1 = row0 + (l15 & 7), r2 = r1 + 8;
+    const unsigned cb = ((unsigned)colq + (low ? 0u : 8u)) * 2u;
+    const unsigned o1 = (col_ok && r1 < p.M) ? (unsigned)r1 * ld * 2u + cb : 0x80000000u;
+    const unsigned o2 = (col_ok && r2 < p.M) ? (unsigned)r2 * ld * 2u + cb : 0x80000000u;
+    __builtin_amdgcn_raw_buffer_store_b128(st1, rs, o1, 0, kStoreAux);
+    __builtin_amdgcn_raw_buffer_store_b128(st2, rs, o2, 0, kStoreAux);
+  };
+
   f32x4 acc[2][4][4];
-  bfrag8 af[4][2], bf0[2][2], bf1[2][2];
+  bfrag8 af[4][2] = {}, bf0[2][2] = {}, bf1[2][2] = {};
 
   auto zero_acc = [&]() {
 #pragma unroll
@@ -265,6 +306,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
         for (int c = 0; c < 4; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto read_a = [&](int copy, int mh) {
+    if (ABL & 2) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(af[mt][ks]));
+      return;
+    }
     const char* u = smem + copy * kCopy + mh * kUnit;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -273,6 +321,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
         af[mt][ks] = *reinterpret_cast<const bfrag8*>(u + (ks ? aoff1 : aoff0) + mt * 2048);
   };
   auto read_b = [&](int copy, int nh, bfrag8 (&bf)[2][2]) {
+    if (ABL & 2) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(bf[nt][ks]));
+      return;
+    }
     const char* u = smem + copy * kCopy + (2 + nh) * kUnit;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -281,6 +336,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
         bf[nt][ks] = *reinterpret_cast<const bfrag8*>(u + (ks ? boff1 : boff0) + nt * 2048);
   };
   auto quadrant = [&](int mh, int nh, const bfrag8 (&bf)[2][2]) {
+    if (ABL & 8) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(af[mt][ks]));
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(bf[nt][ks]));
+      }
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -291,66 +356,101 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // Phase = memory section (fragment reads, one unit refill, counted wait) + compute section (16 MFMAs).
+  // SYNC 0: a barrier after each section, the second wave group one barrier behind the first, so the
+  // groups strictly alternate between the sections. SYNC 1: one barrier per phase, after the compute
+  // section for the first group and between the sections for the second, so that inside every barrier
+  // interval one group runs memory -> compute and the other compute -> memory. Either way a unit is
+  // waited for one phase before its first read and refilled two phases after its last.
+  auto sync_mc = [&]() {
+    if (ABL & 4) return;
+    if (SYNC == 0 || wr == 1) barrier();
+  };
+  auto sync_cm = [&]() {
+    if (ABL & 4) return;
+    if (SYNC == 0 || wr == 0) barrier();
+  };
   // One K-tile = four phases; W = vector-memory operations allowed to stay in flight at each wait
   // (8 = the four most recent units; + the epilogue's stores while they are younger than the unit
   // being waited for).
-  auto ktile = [&](int kt, int copy, auto wtag) {
-    constexpr int W = decltype(wtag)::value;
+  auto ktile = [&](int kt, int copy, auto cfg) {
+    using Cfg = decltype(cfg);
     // phase 0: quadrant (rows 0-63, columns 0-31)
     read_a(copy, 0);
     read_b(copy, 0, bf0);
-    issue(TB{}, H1{}, kt + 1, copy ^ 1);
-    wait_vm<W>();
-    barrier();
+    if (Cfg::kIssue01) issue(TB{}, H1{}, kt + 1, copy ^ 1);
+    wait_vm<Cfg::kW0>();
+    sync_mc();
     quadrant(0, 0, bf0);
-    barrier();
+    sync_cm();
     // phase 1: (rows 0-63, columns 32-63)
     read_b(copy, 1, bf1);
-    issue(TA{}, H1{}, kt + 1, copy ^ 1);
-    wait_vm<W>();
-    barrier();
+    if (Cfg::kIssue01) issue(TA{}, H1{}, kt + 1, copy ^ 1);
+    wait_vm<Cfg::kW1>();
+    sync_mc();
     quadrant(0, 1, bf1);
-    barrier();
+    sync_cm();
     // phase 2: (rows 64-127, columns 32-63)
     read_a(copy, 1);
     issue(TA{}, H0{}, kt + 2, copy);
-    wait_vm<W>();
-    barrier();
+    wait_vm<Cfg::kW2>();
+    sync_mc();
     quadrant(1, 1, bf1);
-    barrier();
+    sync_cm();
     // phase 3: (rows 64-127, columns 0-31), operands already in registers
     issue(TB{}, H0{}, kt + 2, copy);
-    wait_vm<W>();
-    barrier();
+    wait_vm<Cfg::kW3>();
+    sync_mc();
     quadrant(1, 0, bf0);
-    barrier();
+    sync_cm();
   };
 
-  // ---- prologue: the first six units of the first tile ----------------------------------------------
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(p.aux_out, 0, (int)p.aux_bytes, 0x00020000);
+  constexpr int kStores = (EPI == kEpiGelu) ? 32 : 16;   // epilogue stores per wave and tile
+
+  // ---- prologue: both K-tile copies of the first tile (the order of the stream) ----------------------
   issue(TA{}, H0{}, 0, 0);
   issue(TB{}, H0{}, 0, 0);
   issue(TB{}, H1{}, 0, 0);
   issue(TA{}, H1{}, 0, 0);
   issue(TA{}, H0{}, 1, 1);
   issue(TB{}, H0{}, 1, 1);
-  wait_vm<8>();
+  issue(TB{}, H1{}, 1, 1);
+  issue(TA{}, H1{}, 1, 1);
+  // as many out-of-range (dropped) stores as an epilogue issues: the first tile then counts its
+  // outstanding operations exactly like every later one
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < kStores; ++i)   // distinct offsets: identical stores would be merged into one
+      __builtin_amdgcn_raw_buffer_store_b128(z, rsC, 0x80000000u + 16u * i, 0, 0);
+  }
+  wait_vm<12 + kStores>();
   barrier();
-  if (wr == 1) barrier();   // the second wave group runs one barrier behind the first
+  if (SYNC == 0 && wr == 1) barrier();   // the second wave group runs one barrier behind the first
 
-  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(p.aux_out, 0, (int)p.aux_bytes, 0x00020000);
-  constexpr int kStores = (EPI == kEpiGelu) ? 32 : 16;   // epilogue stores per wave and tile
 
   int copy = 0;
   for (int it = 0; it < ntiles; ++it) {
     zero_acc();
-    if (it == 0) ktile(0, copy, std::integral_constant<int, 8>{});
-    else ktile(0, copy, std::integral_constant<int, 8 + kStores>{});
+    // Waits: a unit is waited for one phase before its first read, leaving in flight the vector-memory
+    // operations issued after it: 8 LDS-DMA pieces in the steady state; in the first K-tile of a tile
+    // two more (its phases 0 and 1 issue nothing: both copies were filled ahead, the last two units
+    // at the start of the previous epilogue), plus that epilogue's stores while they are younger than
+    // the unit in question (through phase 1 of the second K-tile).
+    ktile(0, copy, KtCfg<10 + kStores, 8 + kStores, 8 + kStores, 8 + kStores, false>{});
     copy ^= 1;
-    for (int kt = 1; kt < nk; ++kt) {
-      ktile(kt, copy, std::integral_constant<int, 8>{});
+    ktile(1, copy, KtCfg<8 + kStores, 8 + kStores, 8, 8, true>{});
+    copy ^= 1;
+    for (int kt = 2; kt < nk; ++kt) {
+      ktile(kt, copy, KtCfg<8, 8, 8, 8, true>{});
       copy ^= 1;
     }
+    // the two units of the next tile's second K-tile whose slots the last K-tile has finished reading:
+    // issued ahead of the stores, so that nothing the next tile needs soon queues behind them
+    issue(TB{}, H1{}, nk + 1, copy ^ 1);
+    issue(TA{}, H1{}, nk + 1, copy ^ 1);
 
     // ---- epilogue (no barriers, no LDS-DMA: only stores, counted in the next tile's first waits) ----
     {
@@ -366,14 +466,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          const int row = cur_m0 + 128 * wr + 64 * mh + 16 * mt + l15;
+          const int row0 = cur_m0 + 128 * wr + 64 * mh + 16 * mt;
+          const int row = row0 + l15;
           const bool ok = col_ok && row < p.M;
           float v[16];
 #pragma unroll
           for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * T + e] = acc[mh][mt][T][e] + (BIAS ? bv[4 * T + e] : 0.f);
-          const unsigned coff = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)colq) * 2u : 0x80000000u;
           if (EPI == kEpiMul || EPI == kEpiAdd) {
             const unsigned xoff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0u;
             const u32x4* xp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux_in) + xoff);
@@ -401,9 +501,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
               g0[j] = pack_bf16x2(d[2 * j], d[2 * j + 1]);
               g1[j] = pack_bf16x2(d[8 + 2 * j], d[8 + 2 * j + 1]);
             }
-            const unsigned goff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(g0, rsG, goff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(g1, rsG, goff + 16, 0, 0);
+            store_rows16(rsG, g0, g1, row0, colq, (unsigned)p.ld_aux, col_ok);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -411,8 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
               o1[j] = pack_bf16x2(v[8 + 2 * j], v[8 + 2 * j + 1]);
             }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(o0, rsC, coff, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(o1, rsC, coff + 16, 0, 0);
+          store_rows16(rsC, o0, o1, row0, colq, (unsigned)p.ldc, col_ok);
         }
     }
     cur_m0 = nxt_m0;
@@ -424,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       nxt_n0 = t2.n0;
     }
   }
-  if (wr == 0) barrier();   // pairs with the extra barrier the second wave group started with
+  if (SYNC == 0 && wr == 0) barrier();   // pairs with the extra barrier the second wave group started with
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (zero-fill) LDS-DMA before the LDS is released
 }
 
@@ -475,6 +572,9 @@ bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long 
   return true;
 }
 
+int g_gemm_nt_variant = 0;   // benchmark knob: bit 0 = one barrier per phase, bit 1 = drop the stores (timing only)
+void gemm_nt_set_variant(int v) { g_gemm_nt_variant = v; }
+
 void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   if (a.M == 0 || a.N == 0) return;
   a.tiles_m = (a.M + 255) / 256;
@@ -483,6 +583,8 @@ void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   a.b_bytes = (unsigned)(((long long)a.N - 1) * a.ldb * 2 + (long long)a.K * 2);
   a.c_bytes = (unsigned)(((long long)a.M - 1) * a.ldc * 2 + (long long)a.N * 2);
   a.aux_bytes = (unsigned)(((long long)a.M - 1) * a.ld_aux * 2 + (long long)a.N * 2);
+  if (g_gemm_nt_variant & 2) a.c_bytes = a.aux_bytes = 0;
+  a.skew_ticks = (g_gemm_nt_variant >> 8);
   const int total = a.tiles_m * a.tiles_n;
   int grid = num_cus > 0 ? num_cus : 256;
   grid &= ~7;
@@ -493,16 +595,34 @@ void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   F(kEpiNone, false) F(kEpiNone, true) F(kEpiGelu, false) F(kEpiGelu, true) F(kEpiMul, false) F(kEpiMul, true) \
   F(kEpiAdd, false) F(kEpiAdd, true)
   if (!attr) {
-#define DPA_GNT_ATTR(E, B) \
-  (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, B>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+#define DPA_GNT_ATTR(E, B)                                                                                        \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, B, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, B, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     DPA_GNT_ALL(DPA_GNT_ATTR)
 #undef DPA_GNT_ATTR
     attr = true;
   }
+#ifdef DPA_GEMM_ABLATE
+  {
+    const int abl = (g_gemm_nt_variant >> 4) & 15;
+#define DPA_GNT_ABL(A)                                                                                       \
+  if (abl == A) {                                                                                            \
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<kEpiNone, false, 0, A>,                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                             \
+    hipLaunchKernelGGL((gemm_nt_kernel<kEpiNone, false, 0, A>), dim3(grid), dim3(512), kLds, st, a);         \
+    return;                                                                                                  \
+  }
+    DPA_GNT_ABL(1) DPA_GNT_ABL(2) DPA_GNT_ABL(3) DPA_GNT_ABL(4) DPA_GNT_ABL(8) DPA_GNT_ABL(9) DPA_GNT_ABL(10) DPA_GNT_ABL(12)
+#undef DPA_GNT_ABL
+  }
+#endif
   const bool bias = a.bias != nullptr;
 #define DPA_GNT_LAUNCH(E, B)                                                                              \
   if (epi == E && bias == B) {                                                                            \
-    hipLaunchKernelGGL((gemm_nt_kernel<E, B>), dim3(grid), dim3(512), kLds, st, a);                       \
+    if (g_gemm_nt_variant & 1)                                                                            \
+      hipLaunchKernelGGL((gemm_nt_kernel<E, B, 1>), dim3(grid), dim3(512), kLds, st, a);                  \
+    else                                                                                                  \
+      hipLaunchKernelGGL((gemm_nt_kernel<E, B, 0>), dim3(grid), dim3(512), kLds, st, a);                  \
     return;                                                                                               \
   }
   DPA_GNT_ALL(DPA_GNT_LAUNCH)

@@ -126,10 +126,12 @@ struct GemmNtArgs {
   long long lda, ldb, ldc, ld_aux;   // row strides in elements
   unsigned a_bytes, b_bytes, c_bytes, aux_bytes;   // filled by gemm_nt()
   int tiles_m, tiles_n;                            // filled by gemm_nt()
+  int skew_ticks;                                  // filled by gemm_nt() (benchmark knob)
 };
 bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
                 bool has_bias);
 void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st);
+void gemm_nt_set_variant(int v);   // benchmark knob, see csrc/gemm_nt.hip
 // out[C, R] = in[R, C]^T (bf16, R % 8 == 0 and C % 8 == 0, contiguous).
 void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
 

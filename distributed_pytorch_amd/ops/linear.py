@@ -1,8 +1,9 @@
-"""Linear layer with a hand-written weight-gradient path.
+"""Linear layer on hand-written GEMMs.
 
-Forward ``y = x @ w.T + b`` and the input gradient ``dx = dy @ w`` are plain library GEMMs
-(hipBLASLt through ``torch``): both contract over a contiguous dimension and run near the
-library's best. The weight gradient ``dw = dy.T @ x`` contracts over the tokens with both
+Forward ``y = x @ w.T + b`` and the input gradient ``dx = dy @ w`` run on the NT MFMA kernel of
+``csrc/gemm_nt.hip`` (bias, GELU / GELU', multiply and add epilogues; the input gradient uses the
+weight transposed once per optimizer step); shapes outside its envelope (fewer than
+``GEMM_MIN_ROWS`` rows, K not a multiple of 64, ...) fall back to the library. The weight gradient ``dw = dy.T @ x`` contracts over the tokens with both
 operands strided; it runs on the split-M MFMA kernel of ``csrc/gemm_wgrad.hip`` (2-3x the
 library on these shapes), which also produces the bias gradient from the tiles it already
 stages instead of a separate column-sum reduction.
@@ -97,6 +98,95 @@ def _direct_bias_target(b_param):
     return g
 
 
+# ---- own NT GEMM (csrc/gemm_nt.hip) -------------------------------------------------------------
+# Forward y = x W^T and input gradient dx = dy W both run on the same kernel (both operands
+# contraction-contiguous): the input gradient takes W^T, transposed once per weight version.
+GEMM_MIN_ROWS = int(os.environ.get("DPA_GEMM_MIN_ROWS", 512))   # below this the 256-row tiles are mostly padding
+_EPI_NONE, _EPI_GELU, _EPI_MUL, _EPI_ADD = 0, 1, 2, 3
+_WT_CACHE: dict = {}
+_WEIGHTS_EPOCH = 0
+
+
+def bump_weights_epoch() -> None:
+    """Called after every in-place parameter update that bypasses autograd's version counter (the
+    fused optimizer kernel): cached transposed weights are stale from here on."""
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
+def transposed_weight(w: torch.Tensor) -> torch.Tensor:
+    """``w.T`` as a contiguous bf16 matrix, cached per weight version (recomputed inside a hipGraph
+    capture, where the replay has to redo it)."""
+    if torch.cuda.is_current_stream_capturing():
+        return ops().transpose_bf16(w.detach())
+    key = (w.data_ptr(), tuple(w.shape))
+    stamp = (_WEIGHTS_EPOCH, w._version)
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent[0] == stamp:
+        return ent[1]
+    wt = ops().transpose_bf16(w.detach())
+    if len(_WT_CACHE) > 4096:
+        _WT_CACHE.clear()
+    _WT_CACHE[key] = (stamp, wt)
+    return wt
+
+
+def _rows_ok(x2: torch.Tensor) -> bool:
+    return x2.shape[0] >= GEMM_MIN_ROWS and x2.stride(1) == 1
+
+
+def gemm_supported(x2: torch.Tensor, w: torch.Tensor, b=None, aux=None) -> bool:
+    return (os.environ.get("DPA_LIBRARY_GEMM", "0") != "1" and x2.is_cuda and x2.dtype == torch.bfloat16
+            and w.dtype == torch.bfloat16 and x2.dim() == 2 and _rows_ok(x2) and w.is_contiguous()
+            and ops().gemm_nt_supported(x2, w, b, aux))
+
+
+def _dx_supported(dy2: torch.Tensor, w: torch.Tensor, aux=None) -> bool:
+    """dx = dy2 [M, N] @ w [N, K] through the NT kernel on w^T [K, N]."""
+    N, K = w.shape
+    if not (os.environ.get("DPA_LIBRARY_GEMM", "0") != "1" and dy2.is_cuda and dy2.dtype == torch.bfloat16
+            and w.dtype == torch.bfloat16 and w.is_contiguous() and _rows_ok(dy2) and N % 64 == 0 and N >= 128
+            and K % 16 == 0 and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and dy2.shape[0] * max(N, K) * 2 < 2 ** 31):
+        return False
+    return aux is None or (aux.stride(1) == 1 and aux.stride(0) % 8 == 0 and aux.data_ptr() % 16 == 0)
+
+
+def _input_grad(dy2: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    if _dx_supported(dy2, w):
+        return ops().gemm_nt(dy2, transposed_weight(w), None, _EPI_NONE, None)[0]
+    return torch.mm(dy2, w)
+
+
+def _param_grads(w_param, b_param, dy2, x2, need_w: bool, need_b: bool):
+    """(dw, db) of a Linear for autograd to accumulate, or (None, None) after folding them straight
+    into the owning engine's flat gradient buffers (``w_param`` / ``b_param`` given and marked
+    ``_dpa_direct``). Returning None for a gradient still runs the parameter's AccumulateGrad node, so
+    post-accumulate hooks (bucket / unit accounting of the engines) fire exactly as for an
+    autograd-accumulated gradient."""
+    dw = db = None
+    target = _direct_target(w_param, dy2, x2) if (w_param is not None and need_w) else None
+    if target is not None:
+        btarget = _direct_bias_target(b_param) if need_b else None
+        if need_b and btarget is None:
+            slabs, dbf = ops().wgrad2_slabs_bias(dy2, x2)
+            db = dbf.to(dy2.dtype)
+            ops().ws_to(slabs, target, True)
+        else:
+            # GEMM + folds of the weight and bias slabs into the flat buffers: one op, no temporaries
+            ops().wgrad2_direct(dy2, x2, target, btarget)
+    elif need_w:
+        if wgrad2_supported(dy2, x2) or wgrad_supported(dy2, x2):
+            dw, db = weight_grad(dy2, x2, need_b)
+        else:
+            dw = torch.mm(dy2.t(), x2)
+            if need_b:
+                db = bias_grad(dy2)
+    elif need_b:
+        db = bias_grad(dy2)
+    return dw, db
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, sole_use):
@@ -104,6 +194,9 @@ class _LinearFn(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.w_param = w if sole_use else None
         ctx.b_param = b if sole_use else None
+        x2 = x.reshape(-1, x.shape[-1])
+        if gemm_supported(x2, w, b):
+            return ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0].view(*x.shape[:-1], w.shape[0])
         return F.linear(x, w, b)
 
     @staticmethod
@@ -111,43 +204,71 @@ class _LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
-        dx = dw = db = None
+        dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, w).view(x.shape)
+            dx = _input_grad(dy2, w).view(x.shape)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        target = None
-        if ctx.w_param is not None and ctx.needs_input_grad[1]:
-            target = _direct_target(ctx.w_param, dy2, x2)
-        if target is not None:
-            # Fold the split slabs straight into the engine's flat gradient buffer (one pass instead
-            # of convert + autograd's accumulate). Returning None for dw still runs the parameter's
-            # AccumulateGrad node, so post-accumulate hooks (bucket / unit accounting of the
-            # engines) fire exactly as they do for an autograd-accumulated gradient.
-            btarget = _direct_bias_target(ctx.b_param) if need_b else None
-            if need_b and btarget is None:
-                slabs, dbf = ops().wgrad2_slabs_bias(dy2, x2)
-                db = dbf.to(dy2.dtype)
-                ops().ws_to(slabs, target, True)
-            else:
-                # GEMM + folds of the weight and bias slabs into the flat buffers: one op, no temporaries
-                ops().wgrad2_direct(dy2, x2, target, btarget)
-        elif ctx.needs_input_grad[1]:
-            if wgrad2_supported(dy2, x2) or wgrad_supported(dy2, x2):
-                dw, db = weight_grad(dy2, x2, need_b)
-            else:
-                dw = torch.mm(dy2.t(), x2)
-                if need_b:
-                    db = bias_grad(dy2)
-        elif need_b:
-            db = bias_grad(dy2)
+        dw, db = _param_grads(ctx.w_param, ctx.b_param, dy2, x2, ctx.needs_input_grad[1], need_b)
         return dx, dw, db, None
+
+
+class _MlpGeluFn(torch.autograd.Function):
+    """``c_proj(gelu(c_fc(x)))`` for the bias-free feed-forward block (reference:
+    single-gpu/model.py:388-398) with the activation inside the GEMM epilogues: the c_fc product
+    writes gelu(h) and gelu'(h) directly (the pre-activation h is never stored), and in backward the
+    input gradient of c_proj comes out of its GEMM already multiplied by gelu'(h)."""
+
+    @staticmethod
+    def forward(ctx, x, w_fc, w_proj, sole_use):
+        x2 = x.reshape(-1, x.shape[-1])
+        act, dact = ops().gemm_nt(x2, w_fc, None, _EPI_GELU, None)
+        y = ops().gemm_nt(act, w_proj, None, _EPI_NONE, None)[0]
+        ctx.save_for_backward(x, w_fc, w_proj, act, dact)
+        ctx.fc_param = w_fc if sole_use else None
+        ctx.proj_param = w_proj if sole_use else None
+        return y.view(*x.shape[:-1], w_proj.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_fc, w_proj, act, dact = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        # dh = (dy W_proj) * gelu'(h): the multiply is the GEMM's epilogue
+        dh = ops().gemm_nt(dy2, transposed_weight(w_proj), None, _EPI_MUL, dact)[0]
+        dw_proj, _ = _param_grads(ctx.proj_param, None, dy2, act, ctx.needs_input_grad[2], False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _input_grad(dh, w_fc).view(x.shape)
+        dw_fc, _ = _param_grads(ctx.fc_param, None, dh, x2, ctx.needs_input_grad[1], False)
+        return dx, dw_fc, dw_proj, None
+
+
+def mlp_gelu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor) -> bool:
+    if not (use_hip(x, w_fc, w_proj) and x.dtype == torch.bfloat16 and w_fc.dtype == torch.bfloat16
+            and w_proj.dtype == torch.bfloat16):
+        return False
+    x2 = x.reshape(-1, x.shape[-1])
+    up, C = w_fc.shape
+    if not gemm_supported(x2, w_fc):
+        return False
+    # shapes of the second product and of the two input-gradient products
+    return (up % 64 == 0 and up >= 128 and C % 64 == 0 and C >= 128 and w_proj.is_contiguous()
+            and tuple(w_proj.shape) == (C, up) and x2.shape[0] * max(up, C) * 2 < 2 ** 31)
+
+
+def mlp_gelu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False) -> torch.Tensor:
+    """Fused feed-forward block with exact-erf GELU; callers check ``mlp_gelu_supported`` first."""
+    return _MlpGeluFn.apply(x, w_fc, w_proj, sole_use)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, sole_use: bool = False) -> torch.Tensor:
     """``x @ w.T + b``. ``sole_use=True`` promises that this call is the only consumer of ``w`` in
     the forward pass, which allows its gradient to be accumulated straight into the owning
     engine's flat gradient buffer (see ``_direct_target``)."""
-    if use_hip(x, w) and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and torch.is_grad_enabled() \
-            and (x.requires_grad or w.requires_grad):
-        return _LinearFn.apply(x, w, b, sole_use)
+    if use_hip(x, w) and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+            return _LinearFn.apply(x, w, b, sole_use)
+        x2 = x.reshape(-1, x.shape[-1])
+        if gemm_supported(x2, w, b):
+            return ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0].view(*x.shape[:-1], w.shape[0])
     return F.linear(x, w, b)

@@ -50,6 +50,8 @@ def adamw_step(master: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Te
         wds = [float(w) for _, w in segments]
         ops().adamw_step(master, exp_avg, exp_avg_sq, grad, param_out, ends, wds, lr, beta1, beta2, eps, step,
                          norm2, max_norm, grad_mul, dyn)
+        from .linear import bump_weights_epoch
+        bump_weights_epoch()   # the kernel rewrote compute weights behind autograd's back: drop cached transposes
         return
     # ---- eager path (CPU plumbing / tests) ----
     g = grad.float() * grad_mul

@@ -744,3 +744,136 @@ def test_kv_append_writes_one_row_at_the_device_position():
     before = kc.clone()
     ops.kv_append(kc, vc, k, v, torch.tensor([S], dtype=torch.int64, device=DEV))   # past the end: nothing is written
     assert torch.equal(kc, before)
+
+
+# ---- NT GEMM with fused epilogues (csrc/gemm_nt.hip) ----------------------------------------------
+def _gemm_ref(a, b, bias):
+    v = a.float() @ b.float().t()
+    return v if bias is None else v + bias.float()
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 752, 192), (4096, 2304, 768), (2600, 768, 3072),
+                                   (33000, 768, 768)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_nt_plain_and_bias(M, N, K, bias):
+    torch.manual_seed(0)
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    bv = (torch.randn(N, device=DEV) * 0.5).bfloat16() if bias else None
+    assert _ops().gemm_nt_supported(a, b, bv, None)
+    c, aux = _ops().gemm_nt(a, b, bv, 0, None)
+    assert aux is None or aux.numel() == 0
+    assert rel_err(c, _gemm_ref(a, b, bv)) < 4e-3
+
+
+def test_gemm_nt_strided_rows():
+    """A read through a row-strided view (a column slice of a wider activation)."""
+    torch.manual_seed(1)
+    wide = torch.randn(2048, 1024, device=DEV).bfloat16()
+    a = wide[:, 256:768]
+    b = (torch.randn(384, 512, device=DEV) * 0.05).bfloat16()
+    c, _ = _ops().gemm_nt(a, b, None, 0, None)
+    assert rel_err(c, _gemm_ref(a, b, None)) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 256), (5000, 3072, 768)])
+def test_gemm_nt_gelu_epilogue(M, N, K):
+    """c = GELU_erf(a b^T + bias), aux = GELU_erf'(a b^T + bias), both against fp32 torch."""
+    torch.manual_seed(2)
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
+    bv = (torch.randn(N, device=DEV) * 0.5).bfloat16()
+    c, aux = _ops().gemm_nt(a, b, bv, 1, None)
+    h = _gemm_ref(a, b, bv).requires_grad_()
+    act = F.gelu(h)
+    act.sum().backward()
+    assert rel_err(c, act) < 4e-3
+    assert rel_err(aux, h.grad) < 4e-3
+    # the erf approximation itself (no bf16 rounding in the way): output error far below bf16 resolution
+    assert (c.float() - act).abs().max().item() < 0.02 * act.abs().max().item()
+
+
+@pytest.mark.parametrize("epi", [2, 3])
+def test_gemm_nt_mul_add_epilogues(epi):
+    torch.manual_seed(3)
+    M, N, K = 3100, 1024, 320
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    x = torch.randn(M, N, device=DEV).bfloat16()
+    c, _ = _ops().gemm_nt(a, b, None, epi, x)
+    v = _gemm_ref(a, b, None)
+    ref = v * x.float() if epi == 2 else v + x.float()
+    assert rel_err(c, ref) < 4e-3
+
+
+def test_gemm_nt_many_tiles_per_workgroup_is_race_free():
+    """The persistent path (several output tiles per workgroup, operand stream running across tile
+    boundaries behind counted waits): bitwise identical results over repeated launches and equal to the
+    reference on every element."""
+    torch.manual_seed(4)
+    M, N, K = 65536, 768, 768
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    first, _ = _ops().gemm_nt(a, b, None, 0, None)
+    ref = _gemm_ref(a, b, None)
+    assert ((first.float() - ref).abs() <= 2e-2 * ref.abs() + 2e-2).all()
+    for _ in range(5):
+        again, _ = _ops().gemm_nt(a, b, None, 0, None)
+        assert torch.equal(first, again)
+
+
+def test_transpose_bf16():
+    x = torch.randn(3072, 768, device=DEV).bfloat16()
+    assert torch.equal(_ops().transpose_bf16(x), x.t().contiguous())
+    y = torch.randn(200, 72, device=DEV).bfloat16()
+    assert torch.equal(_ops().transpose_bf16(y), y.t().contiguous())
+
+
+def test_linear_fwd_bwd_on_own_gemm():
+    """ops.linear forward / input gradient on the NT kernel (bias epilogue, transposed-weight cache)
+    and the weight / bias gradients, against fp32 autograd."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(5)
+    M, K, N = 4096, 768, 2304
+    x = torch.randn(M, K, device=DEV).bfloat16().requires_grad_()
+    w = (torch.randn(N, K, device=DEV) * 0.05).bfloat16().requires_grad_()
+    bv = (torch.randn(N, device=DEV) * 0.5).bfloat16().requires_grad_()
+    dy = torch.randn(M, N, device=DEV).bfloat16()
+    assert ops.linear.__module__.endswith("linear")
+    y = ops.linear(x, w, bv)
+    y.backward(dy)
+    xr, wr, br = [t.detach().float().requires_grad_() for t in (x, w, bv)]
+    yr = F.linear(xr, wr, br)
+    yr.backward(dy.float())
+    assert rel_err(y, yr) < 4e-3
+    assert rel_err(x.grad, xr.grad) < 4e-3
+    assert rel_err(w.grad, wr.grad) < 6e-3
+    assert rel_err(bv.grad, br.grad) < 6e-3
+    # a changed weight (version counter) must not be served from the transposed-weight cache
+    with torch.no_grad():
+        w.mul_(2.0)
+    x.grad = None
+    ops.linear(x, w, bv).backward(dy)
+    assert rel_err(x.grad, 2 * xr.grad) < 4e-3
+
+
+def test_mlp_gelu_fused_fwd_bwd():
+    """Fused feed-forward block (GELU / GELU' in the GEMM epilogues) against fp32 autograd of
+    c_proj(gelu(c_fc(x)))."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(6)
+    M, C, U = 4096, 768, 3072
+    x = torch.randn(M, C, device=DEV).bfloat16().requires_grad_()
+    w1 = (torch.randn(U, C, device=DEV) * 0.05).bfloat16().requires_grad_()
+    w2 = (torch.randn(C, U, device=DEV) * 0.05).bfloat16().requires_grad_()
+    dy = torch.randn(M, C, device=DEV).bfloat16()
+    assert ops.mlp_gelu_supported(x, w1, w2)
+    y = ops.mlp_gelu(x, w1, w2)
+    y.backward(dy)
+    xr, w1r, w2r = [t.detach().float().requires_grad_() for t in (x, w1, w2)]
+    yr = F.linear(F.gelu(F.linear(xr, w1r)), w2r)
+    yr.backward(dy.float())
+    assert rel_err(y, yr) < 6e-3
+    assert rel_err(x.grad, xr.grad) < 8e-3
+    assert rel_err(w1.grad, w1r.grad) < 8e-3
+    assert rel_err(w2.grad, w2r.grad) < 8e-3
