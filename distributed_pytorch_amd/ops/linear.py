@@ -13,6 +13,7 @@ Reference behaviour: ``nn.Linear`` (reference: single-gpu/model.py:112-114,373-3
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -119,15 +120,17 @@ def transposed_weight(w: torch.Tensor) -> torch.Tensor:
     capture, where the replay has to redo it)."""
     if torch.cuda.is_current_stream_capturing():
         return ops().transpose_bf16(w.detach())
-    key = (w.data_ptr(), tuple(w.shape))
-    stamp = (_WEIGHTS_EPOCH, w._version)
+    # Keyed by the weight tensor itself, not by its address: engines that gather parameters into
+    # recycled buffers (fully sharded units) put different weights of equal shape at the same address.
+    key = id(w)
+    stamp = (_WEIGHTS_EPOCH, w._version, w.data_ptr())
     ent = _WT_CACHE.get(key)
-    if ent is not None and ent[0] == stamp:
+    if ent is not None and ent[0] == stamp and ent[2]() is w:
         return ent[1]
     wt = ops().transpose_bf16(w.detach())
     if len(_WT_CACHE) > 4096:
         _WT_CACHE.clear()
-    _WT_CACHE[key] = (stamp, wt)
+    _WT_CACHE[key] = (stamp, wt, weakref.ref(w))
     return wt
 
 
