@@ -30,17 +30,21 @@ from distributed_pytorch_amd.parallel import comm  # noqa: E402
 from distributed_pytorch_amd.trainer import build_engine, get_lr  # noqa: E402
 from distributed_pytorch_amd.utils.metrics import PEAK_BF16_DENSE_FLOPS, mfu, model_flops_per_token  # noqa: E402
 
-# tokens/s of the reference's own single-GPU trainer loop (eager PyTorch, bf16 autocast, fused
-# AdamW, no torch.compile: there is no Triton on this image) for GPT-2-124M at micro-batch 16 on
-# one MI355X, measured with benchmarks/reference_baseline.py. None until measured.
-REFERENCE_TOKENS_PER_S_PER_GPU = 446_660.0   # micro-batch 32 (409_953 at micro-batch 16)
+# tokens/s per GPU of the reference's own single-GPU trainer loop (eager PyTorch, bf16 autocast, fused
+# AdamW, no torch.compile: there is no Triton on this image) for GPT-2-124M at T = 1024 on one MI355X,
+# measured with benchmarks/reference_baseline.py, keyed by micro-batch. `vs_baseline` uses the
+# reference's BEST micro-batch: the reference gains nothing from a larger one (its loop is launch- and
+# elementwise-bound), so this is the strongest denominator available.
+REFERENCE_TOKENS_PER_S_PER_GPU = {16: 409_953.0, 32: 446_660.0}
+BASELINE_SOURCE = ("self-measured reference loop (reference model + its trainer loop, bf16 autocast, fused AdamW, "
+                   "no torch.compile), best of micro-batch 16 / 32, benchmarks/reference_baseline.py")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)    # the pinned protocol: median over >= 50 steps
+    ap.add_argument("--warmup", type=int, default=10)   # after >= 10 warm-up steps
     ap.add_argument("--mode", type=str, default="ddp", choices=["single", "ddp", "zero1", "zero2", "fsdp", "fsdp_keep", "ep", "ep_fsdp"])
     ap.add_argument("--model", type=str, default="gpt2-124m", choices=sorted(PRESETS))
     ap.add_argument("--batch", type=int, default=64, help="micro-batch (sequences) per GPU")
@@ -50,6 +54,12 @@ def main():
     ap.add_argument("--act_recomp", action="store_true")
     ap.add_argument("--act_recomp_scope", type=str, default="attn", choices=["attn", "block"])
     ap.add_argument("--hip_graph", action="store_true", help="replay the optimizer step from one hipGraph (1 GPU)")
+    ap.add_argument("--grad_dtype", type=str, default="bf16", choices=["bf16", "fp32"],
+                    help="dtype of the flat gradient buffers and of the gradient collectives")
+    ap.add_argument("--rccl_max_channels", type=int, default=0, help="NCCL_MAX_NCHANNELS for RCCL (0: leave alone)")
+    ap.add_argument("--rccl_min_channels", type=int, default=0, help="NCCL_MIN_NCHANNELS for RCCL (0: leave alone)")
+    ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high"],
+                    help="priority of the HIP stream the collectives run on")
     args = ap.parse_args()
 
     # stdout carries exactly one line (the JSON result): everything else that native libraries print
@@ -61,6 +71,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py measures on the GPU"
+    comm.configure_rccl_env(max_channels=args.rccl_max_channels, min_channels=args.rccl_min_channels,
+                            stream_priority=args.comm_priority)
     dist_job = world > 1 or comm.FORCE_COLLECTIVES   # DPA_FORCE_DIST=1: rehearse the RCCL paths with one rank
     mode = args.mode if dist_job else ("single" if args.mode == "ddp" else args.mode)
     info = comm.init_distributed() if dist_job else comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "none")
@@ -76,7 +88,7 @@ def main():
     global_batch = B * world * args.accum
     tc = Trainconfig(dataset="synthetic", total_batch_size=global_batch * T, batch_size=B,
                      max_iters=args.steps + args.warmup, learning_rate=3e-4, warmup_steps=10, grad_clip=1.0,
-                     bucket_mb=args.bucket_mb, dtype="bf16")
+                     bucket_mb=args.bucket_mb, dtype="bf16", grad_dtype=args.grad_dtype)
 
     data_dir = ensure_synthetic(os.path.join("/tmp", f"dpa_bench_data_v{mc.vocab_size}"), 1 << 24, mc.vocab_size, info.rank)
     check_vocab(os.path.join(data_dir, "train.bin"), mc.vocab_size)
@@ -124,24 +136,42 @@ def main():
         step = graph_step   # noqa: F811 - same contract, submitted as one graph
     for it in range(args.warmup):
         loss = step(it)
+    # what RCCL really spans: an all-reduce of ones over the job's process group
+    rccl_ranks = 1
+    if dist_job:
+        ones = torch.ones(1, dtype=torch.float32, device=info.device)
+        comm.all_reduce(ones)
+        rccl_ranks = int(round(ones.item()))
+    for k in comm.STATS:
+        comm.STATS[k] = 0
+    # Timed region: exactly args.steps steps between two (barrier + device synchronize) pairs; the whole
+    # span is the throughput denominator. Each step is additionally bracketed by HIP events (no host
+    # synchronisation inside the region) for the median / p10 / p90 step times.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for it in range(args.warmup, args.warmup + args.steps):
+    marks[0].record()
+    for i, it in enumerate(range(args.warmup, args.warmup + args.steps)):
         loss = step(it)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=info.device)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    stats = torch.tensor([elapsed, step_ms[len(step_ms) // 2], step_ms[int(0.1 * (len(step_ms) - 1))],
+                          step_ms[int(round(0.9 * (len(step_ms) - 1)))]], dtype=torch.float64, device=info.device)
     if dist_job:
-        comm.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-    elapsed = el.item()
+        comm.all_reduce(stats, op=torch.distributed.ReduceOp.MAX)
+    elapsed, med_ms, p10_ms, p90_ms = stats.tolist()
     final_loss = loss.item() * args.accum
+    comm_bytes = {k: int(v) for k, v in comm.STATS.items() if v}
 
     if info.rank == 0:
         tokens = global_batch * T * args.steps
         tps = tokens / elapsed
-        ref = REFERENCE_TOKENS_PER_S_PER_GPU if (args.model == "gpt2-124m" and T == 1024) else None
+        ref = max(REFERENCE_TOKENS_PER_S_PER_GPU.values()) if (args.model == "gpt2-124m" and T == 1024) else None
+        tokens_step = global_batch * T
         out = {
             "metric": "tokens_per_sec", "value": tps, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000 * elapsed / args.steps, "higher_is_better": True,
@@ -149,6 +179,12 @@ def main():
             "data": "synthetic", "mfu": mfu(tps, flops_tok, world), "peak_flops_per_gpu": PEAK_BF16_DENSE_FLOPS,
             "flops_per_token": flops_tok, "final_loss": final_loss,
             "mem_gb": torch.cuda.max_memory_allocated() / 1024 ** 3,
+            "baseline_source": BASELINE_SOURCE if ref else None,
+            "step_ms": {"median": med_ms, "mean": 1000 * elapsed / args.steps, "p10": p10_ms, "p90": p90_ms},
+            "tokens_per_sec_median_step": tokens_step / (med_ms * 1e-3),
+            "rccl_ranks": rccl_ranks, "comm_bytes_per_step": {k: v // args.steps for k, v in comm_bytes.items()},
+            "n_buckets": len(getattr(engine, "groups", [])), "grad_dtype": args.grad_dtype,
+            "rccl_env": comm.rccl_settings(),
             "config": {"model": args.model, "params": total, "global_batch": global_batch, "micro_batch": B,
                        "seq_len": T, "grad_accum": args.accum,
                        "parallelism": f"{mode}{world}" if world > 1 else "single", "optimizer": "fused AdamW",

@@ -100,6 +100,9 @@ class Trainconfig:
     dtype: str = "auto"               # 'auto' -> bf16 on GPU, fp32 on CPU; or 'bf16' / 'fp32'
     grad_dtype: str = "auto"          # dtype of the flat gradient buffer / gradient collectives
     bucket_mb: float = 48.0           # gradient bucket size for DDP / ZeRO
+    rccl_max_channels: int = 0        # NCCL_MAX_NCHANNELS of the RCCL communicator (0: RCCL's choice)
+    rccl_min_channels: int = 0        # NCCL_MIN_NCHANNELS (0: RCCL's choice)
+    comm_priority: str = "default"    # priority of the stream the collectives run on: default | high
     data_dir: str = ""                # overrides ../data/<dataset>
     synthetic_tokens: int = 0         # >0: generate a synthetic uint16 token stream of that length
     seed: int = 1729
@@ -219,6 +222,9 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--dtype", type=str, default=tc.dtype, choices=["auto", "bf16", "fp32"])
     p.add_argument("--grad_dtype", type=str, default=tc.grad_dtype, choices=["auto", "bf16", "fp32"])
     p.add_argument("--bucket_mb", type=float, default=tc.bucket_mb)
+    p.add_argument("--rccl_max_channels", type=int, default=tc.rccl_max_channels)
+    p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels)
+    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high"])
     p.add_argument("--data_dir", type=str, default=tc.data_dir)
     p.add_argument("--synthetic_tokens", type=str, default=str(tc.synthetic_tokens))
     p.add_argument("--seed", type=int, default=tc.seed)

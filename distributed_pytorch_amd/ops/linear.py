@@ -81,7 +81,9 @@ def _direct_target(w_param, dy2, x2):
     accumulation (``_dpa_direct``) and the kernel can write it, else None."""
     if not getattr(w_param, "_dpa_direct", False):
         return None
-    g = w_param.grad
+    g = getattr(w_param, "_dpa_grad32", None)   # the engine's fp32 gradient buffer, if it keeps one
+    if g is None:
+        g = w_param.grad
     if g is None or g.dtype not in (torch.bfloat16, torch.float32) or not g.is_contiguous() \
             or g.data_ptr() % 16 != 0 or g.numel() % 8 != 0:
         return None
@@ -92,7 +94,9 @@ def _direct_bias_target(b_param):
     """The flat-buffer gradient view of a bias that asked for direct accumulation, else None."""
     if b_param is None or not getattr(b_param, "_dpa_direct", False):
         return None
-    g = b_param.grad
+    g = getattr(b_param, "_dpa_grad32", None)
+    if g is None:
+        g = b_param.grad
     if g is None or g.dtype not in (torch.bfloat16, torch.float32) or not g.is_contiguous() \
             or g.data_ptr() % 16 != 0 or g.numel() % 8 != 0:
         return None

@@ -188,7 +188,11 @@ def _act_bwd(da, h, act):
 
 def _direct_grad(p):
     """The flat-buffer gradient view of ``p`` if its engine asked for direct accumulation, else None."""
-    g = p.grad if getattr(p, "_dpa_direct", False) else None
+    g = None
+    if getattr(p, "_dpa_direct", False):
+        g = getattr(p, "_dpa_grad32", None)
+        if g is None:
+            g = p.grad
     if g is not None and g.is_contiguous() and g.dtype in (torch.bfloat16, torch.float32) \
             and g.data_ptr() % 16 == 0 and g.numel() % 8 == 0:
         return g

@@ -48,11 +48,37 @@ class DistInfo:
         return self.rank == 0
 
 
-def configure_rccl_env():
+_SETTINGS = {"stream_priority": "default"}
+
+
+def configure_rccl_env(max_channels: int = 0, min_channels: int = 0, stream_priority: str | None = None):
+    """Environment of the RCCL communicator; call before ``init_distributed``.
+
+    ``max_channels`` / ``min_channels`` (> 0) bound the number of RCCL channels, i.e. of workgroups
+    (CUs) a collective's kernel occupies beside the backward pass: on the full xGMI mesh a handful of
+    channels per peer saturates the links, and every channel beyond that only takes CUs away from the
+    MFMA kernels. ``stream_priority`` ("default" | "high") is the priority of the HIP stream the
+    collectives run on (high: a ready collective's kernel is scheduled ahead of queued compute
+    kernels, so a bucket leaves as soon as it is complete)."""
     # dmabuf IPC is the only mode the host driver supports on this pool.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # Keep the rendezvous on the loopback interface: container hostnames may not resolve.
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if max_channels > 0:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))
+    if min_channels > 0:
+        os.environ["NCCL_MIN_NCHANNELS"] = str(int(min_channels))
+    if stream_priority is not None:
+        assert stream_priority in ("default", "high"), stream_priority
+        _SETTINGS["stream_priority"] = stream_priority
+
+
+def rccl_settings() -> dict:
+    """What the communicator was (or will be) configured with: for result records."""
+    return {"NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+            "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+            "stream_priority": _SETTINGS["stream_priority"],
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
 
 def arm_hang_dump():
@@ -86,6 +112,10 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
         kwargs = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
             kwargs["device_id"] = device
+            if _SETTINGS["stream_priority"] == "high":
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kwargs["pg_options"] = opts
         restart = int(os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") or 0)
         if restart > 0:
             # Relaunched by torchrun --max-restarts: the agent's key-value store still holds the dead

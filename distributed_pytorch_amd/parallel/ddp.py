@@ -58,6 +58,7 @@ class DDPEngine(Engine):
             self._next -= 1
 
     def _pre_forward(self):
+        super()._pre_forward()
         for gi, g in enumerate(self.groups):
             self._pending[gi] = len(g.slots)
         if self.require_backward_grad_sync:
@@ -90,7 +91,9 @@ class DDPEngine(Engine):
             ops().spin(blocks, usec, sink)
 
     def _reduce_group(self, gi: int):
-        return comm.all_reduce(self.groups[gi].grad, group=self.group, async_op=True)
+        g = self.groups[gi]
+        g.fold()
+        return comm.all_reduce(g.rgrad, group=self.group, async_op=True)
 
     def finish_grad_sync(self):
         if not self._dist:

@@ -64,10 +64,14 @@ class Engine(nn.Module):
     name = "single"
 
     def __init__(self, model: nn.Module, weight_decay: float = 0.1, lr: float = 3e-4, betas=(0.9, 0.999),
-                 eps: float = 1e-8, dtype: str = "auto", bucket_mb: float = 48.0, device=None, group=None):
+                 eps: float = 1e-8, dtype: str = "auto", bucket_mb: float = 48.0, device=None, group=None,
+                 grad_dtype: str = "auto"):
         super().__init__()
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         self.param_dtype = resolve_dtype(dtype, self.device)
+        # "auto" / "bf16": gradients in the parameter dtype; "fp32": fp32 accumulation and reduction
+        assert grad_dtype in ("auto", "bf16", "fp32"), grad_dtype
+        self.grad_dtype = torch.float32 if grad_dtype == "fp32" else self.param_dtype
         self.module = model.to(self.device)
         self.group = group
         self.world = comm.world_size(group)
@@ -107,7 +111,8 @@ class Engine(nn.Module):
 
     def _build_storage(self):
         plan = plan_groups(self.module, self._bucket_elems())
-        self.groups = [FlatGroup(np_, self.param_dtype, self.device, self._pad_multiple(), self.weight_decay, name)
+        self.groups = [FlatGroup(np_, self.param_dtype, self.device, self._pad_multiple(), self.weight_decay, name,
+                                 grad_dtype=self.grad_dtype)
                        for name, np_ in plan]
         self.optims = [FlatAdamW(g, *self._opt_range(g), betas=self.betas, eps=self.eps) for g in self.groups]
         for g in self.groups:
@@ -149,7 +154,10 @@ class Engine(nn.Module):
         return self.module(*args, **kwargs)
 
     def _pre_forward(self):
-        pass
+        # fp32 gradient buffers: what the previous micro-step left in the bf16 views joins the fp32 sums
+        # now, so accumulation over micro-steps never happens in bf16
+        if self.grad_dtype != self.param_dtype and torch.is_grad_enabled():
+            self._fold_grads()
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -187,8 +195,14 @@ class Engine(nn.Module):
         self._compute_norm()
         return self._norm2.sqrt() * abs(self._grad_mul())
 
+    def _fold_grads(self):
+        """fp32 gradient buffers: fold what autograd left in the bf16 views (no-op otherwise)."""
+        for g in self.groups:
+            g.fold()
+
     def _compute_norm(self):
         from .flat import grad_norm_sq
+        self._fold_grads()
         grad_norm_sq(self._norm_grads(), self._norm2, None)
         self._reduce_norm()
         self._have_norm = True
@@ -209,7 +223,7 @@ class Engine(nn.Module):
 
     def _apply_updates(self, lr: float):
         for g, o in zip(self.groups, self.optims):
-            o.step(g.grad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
+            o.step(g.rgrad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
                    self._grad_mul(), self._dyn)
 
     def _post_step(self):

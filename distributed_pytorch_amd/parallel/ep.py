@@ -148,7 +148,8 @@ class EPEngine(DDPEngine):
             p.requires_grad_(True)
         self._n_dense_groups = len(self.groups)
         if local_named:
-            g = FlatGroup(local_named, self.param_dtype, self.device, 8, self.weight_decay, "experts")
+            g = FlatGroup(local_named, self.param_dtype, self.device, 8, self.weight_decay, "experts",
+                          grad_dtype=self.grad_dtype)
             self.groups.append(g)
             self.optims.append(FlatAdamW(g, 0, g.numel, betas=self.betas, eps=self.eps))
             g.drop_init()
@@ -156,27 +157,36 @@ class EPEngine(DDPEngine):
             self._launched.append(True)
             self._enable_direct_grads()   # the base class marked its groups before this one existed
 
+    def _skip_expert_groups(self):
+        """Expert gradients are complete locally: nothing to reduce, and no hook counts them down. The
+        last-to-first launch order of the dense buckets therefore starts below them (left at the expert
+        group, whose count never reaches zero, it would hold every dense all-reduce back until
+        finish_grad_sync and lose the overlap with backward)."""
+        for gi in range(self._n_dense_groups, len(self.groups)):
+            self._launched[gi] = True
+            self._pending[gi] = 0
+        self._next = self._n_dense_groups - 1
+
     def _pre_forward(self):
         super()._pre_forward()
-        for gi in range(self._n_dense_groups, len(self.groups)):
-            self._launched[gi] = True      # expert gradients are complete locally: nothing to reduce
+        self._skip_expert_groups()
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad()
-        for gi in range(self._n_dense_groups, len(self.groups)):
-            self._launched[gi] = True
+        self._skip_expert_groups()
 
     def _compute_norm(self):
         """||g||^2 = dense part (replicated, counted once) + sum over ranks of the expert parts."""
         dense = torch.zeros_like(self._norm2)
         first = True
+        self._fold_grads()
         for g in self.groups[:self._n_dense_groups]:
-            ops.sumsq(g.grad, dense, accumulate=not first)
+            ops.sumsq(g.rgrad, dense, accumulate=not first)
             first = False
         expert = torch.zeros_like(self._norm2)
         first = True
         for g in self.groups[self._n_dense_groups:]:
-            ops.sumsq(g.grad, expert, accumulate=not first)
+            ops.sumsq(g.rgrad, expert, accumulate=not first)
             first = False
         comm.all_reduce(expert, group=self.group)
         self._norm2.copy_(dense + expert)
@@ -262,7 +272,8 @@ class EPFSDPEngine(FSDPEngine):
             p.requires_grad_(True)
         self.expert_group = self.expert_optim = None
         if local_named:
-            g = FlatGroup(local_named, self.param_dtype, self.device, 8, self.weight_decay, "experts")
+            g = FlatGroup(local_named, self.param_dtype, self.device, 8, self.weight_decay, "experts",
+                          grad_dtype=self.grad_dtype)
             self.expert_group = g
             self.expert_optim = FlatAdamW(g, 0, g.numel, betas=self.betas, eps=self.eps)
             self.optims.append(self.expert_optim)    # checkpointed with the unit optimizers
@@ -283,7 +294,8 @@ class EPFSDPEngine(FSDPEngine):
             ops.sumsq(u.grad_shard, self._norm2, accumulate=not first)
             first = False
         if self.expert_group is not None:
-            ops.sumsq(self.expert_group.grad, self._norm2, accumulate=True)
+            self.expert_group.fold()
+            ops.sumsq(self.expert_group.rgrad, self._norm2, accumulate=True)
         comm.all_reduce(self._norm2, group=self.group)
         self._have_norm = True
 
@@ -291,7 +303,7 @@ class EPFSDPEngine(FSDPEngine):
         super()._apply_updates(lr)
         if self.expert_group is not None:
             g, o = self.expert_group, self.expert_optim
-            o.step(g.grad, g.data, lr, self.step_count, self._norm2, self._max_norm, self._grad_mul(), self._dyn)
+            o.step(g.rgrad, g.data, lr, self.step_count, self._norm2, self._max_norm, self._grad_mul(), self._dyn)
 
     def _refresh_params_from_master(self):
         if self.expert_group is not None:

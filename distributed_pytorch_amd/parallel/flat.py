@@ -10,6 +10,13 @@ vector-aligned shards for reduce-scatter / all-gather without repacking.
 * ``FlatGroup.data``  : compute-dtype buffer; each ``Parameter.data`` is a view into it.
 * ``FlatGroup.grad``  : gradient buffer of the same dtype; each ``Parameter.grad`` is a view,
   so autograd accumulates straight into the buffer that the collectives send.
+* ``FlatGroup.grad32``: with ``grad_dtype=torch.float32`` on bf16 parameters, the fp32 buffer that
+  accumulates over micro-steps, is reduced across ranks and feeds the optimizer (the reference
+  accumulates and all-reduces fp32 gradients: fp32 parameters under autocast, reference:
+  single-gpu/train.py:338-345). The weight-gradient kernels add their fp32 partial sums straight
+  into it (``Parameter._dpa_grad32``); what autograd accumulates into the bf16 ``grad`` views
+  (embedding rows, LayerNorm, ...) is folded in by ``fold()`` before a collective or the step.
+  ``FlatGroup.rgrad`` names whichever buffer is the one to reduce and to step on.
 * ``FlatAdamW``       : fp32 master / exp_avg / exp_avg_sq for an element range of a group
   (the whole group, or this rank's shard) + the fused step.
 
@@ -49,9 +56,11 @@ class FlatGroup:
     """One contiguous group of parameters (a bucket / FSDP unit)."""
 
     def __init__(self, named_params: Sequence[tuple[str, nn.Parameter]], dtype: torch.dtype, device,
-                 pad_multiple: int = 8, weight_decay: float = 0.0, name: str = ""):
+                 pad_multiple: int = 8, weight_decay: float = 0.0, name: str = "", grad_dtype: torch.dtype | None = None):
         self.name = name
         self.dtype = dtype
+        self.wide_grad = grad_dtype == torch.float32 and dtype != torch.float32
+        self.grad32: torch.Tensor | None = None
         self.device = torch.device(device)
         self.weight_decay = weight_decay
         decay = [(n, p) for n, p in named_params if p.dim() >= 2]
@@ -82,10 +91,30 @@ class FlatGroup:
     def attach_grads(self):
         if self.grad is None:
             self.grad = torch.zeros(self.numel, dtype=self.dtype, device=self.device)
+        if self.wide_grad and self.grad32 is None:
+            self.grad32 = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self._attach_views()
+
+    def _attach_views(self):
         for s in self.slots:
             s.param.grad = self.grad[s.offset:s.offset + s.numel].view(s.shape)
+            if self.grad32 is not None:
+                s.param._dpa_grad32 = self.grad32[s.offset:s.offset + s.numel].view(s.shape)
+
+    @property
+    def rgrad(self) -> torch.Tensor:
+        """The gradient buffer that is reduced across ranks and handed to the optimizer."""
+        return self.grad32 if self.grad32 is not None else self.grad
+
+    def fold(self):
+        """fp32 gradients: move what autograd accumulated in the bf16 views into the fp32 buffer."""
+        if self.grad32 is not None:
+            self.grad32.add_(self.grad)
+            self.grad.zero_()
 
     def zero_grad(self):
+        if self.grad32 is not None:
+            self.grad32.zero_()
         if self.grad is not None:
             self.grad.zero_()
             for s in self.slots:  # re-attach in case somebody replaced .grad
@@ -205,7 +234,7 @@ def grad_norm_sq(groups: Iterable[FlatGroup], out: torch.Tensor, ranges=None) ->
     first = True
     for i, g in enumerate(groups):
         lo, hi = (0, g.numel) if ranges is None else ranges[i]
-        ops.sumsq(g.grad[lo:hi], out, accumulate=not first)
+        ops.sumsq(g.rgrad[lo:hi], out, accumulate=not first)
         first = False
     if first:
         out.zero_()

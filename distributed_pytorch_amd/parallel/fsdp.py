@@ -42,14 +42,16 @@ from .flat import FlatAdamW, FlatGroup, plan_groups
 class FSDPUnit(FlatGroup):
     """A FlatGroup whose full parameter / gradient buffers exist only while needed."""
 
-    def __init__(self, named_params, dtype, device, world, rank, weight_decay, name):
+    def __init__(self, named_params, dtype, device, world, rank, weight_decay, name, grad_dtype=None):
         self._defer_grad = True
-        super().__init__(named_params, dtype, device, 8 * world, weight_decay, name)
+        super().__init__(named_params, dtype, device, 8 * world, weight_decay, name, grad_dtype=grad_dtype)
         self.world, self.rank = world, rank
         self.shard_numel = self.numel // world
         self.lo, self.hi = rank * self.shard_numel, (rank + 1) * self.shard_numel
         self.shard = self.data[self.lo:self.hi].clone()                       # persistent bf16 shard
-        self.grad_shard = torch.zeros(self.shard_numel, dtype=dtype, device=self.device)
+        # the reduce-scatter's output and the optimizer's input: fp32 with fp32 gradient buffers
+        self.grad_shard = torch.zeros(self.shard_numel, dtype=torch.float32 if self.wide_grad else dtype,
+                                      device=self.device)
         self._nbytes = self.data.untyped_storage().nbytes()
         self.gathered = True
         self.gather_work = None
@@ -93,18 +95,30 @@ class FSDPUnit(FlatGroup):
             return
         if self.grad is None:
             self.grad = torch.zeros(self.numel, dtype=self.dtype, device=self.device)
+            if self.wide_grad:
+                self.grad32 = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         else:
             self.grad.untyped_storage().resize_(self._nbytes)
             self.grad.zero_()
-        for s in self.slots:
-            s.param.grad = self.grad[s.offset:s.offset + s.numel].view(s.shape)
+            if self.grad32 is not None:
+                self.grad32.untyped_storage().resize_(2 * self._nbytes)
+                self.grad32.zero_()
+        self._attach_views()
         self.grad_alive = True
+
+    def fold(self):
+        if self.grad_alive:
+            super().fold()
 
     def release_grad(self):
         if self.grad_alive:
             for s in self.slots:
                 s.param.grad = None
+                if self.grad32 is not None:
+                    s.param._dpa_grad32 = None
             self.grad.untyped_storage().resize_(0)
+            if self.grad32 is not None:
+                self.grad32.untyped_storage().resize_(0)
             self.grad_alive = False
 
 
@@ -121,7 +135,8 @@ class FSDPEngine(Engine):
         self.units: list[FSDPUnit] = []
         self.optims = []
         for name, np_ in plan:
-            u = FSDPUnit(np_, self.param_dtype, self.device, self.world, self.rank, self.weight_decay, name)
+            u = FSDPUnit(np_, self.param_dtype, self.device, self.world, self.rank, self.weight_decay, name,
+                         grad_dtype=self.grad_dtype)
             self.units.append(u)
             self.optims.append(FlatAdamW(u, u.lo, u.hi, betas=self.betas, eps=self.eps))
             u.drop_init()
@@ -188,7 +203,8 @@ class FSDPEngine(Engine):
     def _reduce_unit(self, u: FSDPUnit):
         if not u.grad_alive:
             return
-        w = comm.reduce_scatter(u.grad_shard, u.grad, group=self.group, async_op=True)
+        u.fold()
+        w = comm.reduce_scatter(u.grad_shard, u.rgrad, group=self.group, async_op=True)
         u.reduced = True
         if u is not self.root and self.reshard_after_forward:
             u.release_params()
@@ -200,6 +216,7 @@ class FSDPEngine(Engine):
 
     # ---- step lifecycle -------------------------------------------------------------------
     def _pre_forward(self):
+        super()._pre_forward()
         for u in self.units:
             u.pending = len(u.slots)
             u.reduced = False
@@ -216,6 +233,8 @@ class FSDPEngine(Engine):
         for u in self.units:
             if u.grad_alive:
                 u.grad.zero_()
+                if u.grad32 is not None:
+                    u.grad32.zero_()
             u.grad_shard.zero_()
         self._have_norm = False
 

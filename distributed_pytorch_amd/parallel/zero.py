@@ -42,17 +42,20 @@ class ZeroEngine(DDPEngine):
 
     def _reduce_group(self, gi: int):
         g, o = self.groups[gi], self.optims[gi]
+        g.fold()
         if self.stage == 1:
-            return comm.all_reduce(g.grad, group=self.group, async_op=True)
+            return comm.all_reduce(g.rgrad, group=self.group, async_op=True)
         # in-place reduce-scatter: the owner's slice of the bucket receives the sum
-        return comm.reduce_scatter(g.grad[o.lo:o.hi], g.grad, group=self.group, async_op=True)
+        return comm.reduce_scatter(g.rgrad[o.lo:o.hi], g.rgrad, group=self.group, async_op=True)
 
     # the global norm is the sum over ranks of the norms of the owned slices
     def _compute_norm(self):
         first = True
         from .. import ops
+        if not self._dist:
+            self._fold_grads()
         for g, o in zip(self.groups, self.optims):
-            ops.sumsq(g.grad[o.lo:o.hi], self._norm2, accumulate=not first)
+            ops.sumsq(g.rgrad[o.lo:o.hi], self._norm2, accumulate=not first)
             first = False
         comm.all_reduce(self._norm2, group=self.group)
         self._have_norm = True
@@ -62,7 +65,7 @@ class ZeroEngine(DDPEngine):
         # the following buckets
         for gi in range(len(self.groups)):
             g, o = self.groups[gi], self.optims[gi]
-            o.step(g.grad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
+            o.step(g.rgrad[o.lo:o.hi], g.data[o.lo:o.hi], lr, self.step_count, self._norm2, self._max_norm,
                    self._grad_mul())
             self._gather_works.append(comm.all_gather(g.data, g.data[o.lo:o.hi], group=self.group, async_op=True))
 

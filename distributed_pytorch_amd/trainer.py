@@ -64,7 +64,7 @@ def estimate_loss(model, tc: Trainconfig, train_loader, val_loader):
 
 def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
     kw = dict(weight_decay=tc.weight_decay, lr=tc.learning_rate, dtype=tc.dtype, bucket_mb=tc.bucket_mb,
-              device=info.device)
+              device=info.device, grad_dtype=tc.grad_dtype)
     if mode == "single":
         from .parallel.engine import Engine
         return Engine(model, **kw)
@@ -87,6 +87,8 @@ def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
 
 
 def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
+    if mode != "single":
+        comm.configure_rccl_env(tc.rccl_max_channels, tc.rccl_min_channels, tc.comm_priority)
     info = comm.init_distributed() if mode != "single" else comm.DistInfo(
         0, 0, 1, torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu"), "none")
     master = info.is_master
