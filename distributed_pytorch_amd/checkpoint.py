@@ -40,13 +40,45 @@ def save_reference_checkpoint(engine_or_model, model_config, train_config, file_
     return file_name + "_ckpt.pt"
 
 
+def _marker(path: str) -> str:
+    return f"{path}.latest"
+
+
+def _gen_file(path: str, it: int, rank: int) -> str:
+    return f"{path}.it{it}.rank{rank}"
+
+
+def _read_marker(path: str):
+    """(latest iteration, previous iteration or None) from the commit marker, or None without one."""
+    import json
+    try:
+        with open(_marker(path)) as f:
+            m = json.load(f)
+        return int(m["iter"]), (int(m["prev"]) if m.get("prev") is not None else None)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _all_ranks(flag: bool, device) -> bool:
+    """True iff ``flag`` holds on every rank."""
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    comm.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    return t.item() > 0
+
+
 def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None,
                 loader_states=None):
-    """Per-rank resume file ``<path>.rank<r>`` (optimizer shards are rank-local)."""
+    """Resume point of iteration ``it`` as one file per rank (optimizer shards are rank-local), committed
+    as a set: every rank writes ``<path>.it<it>.rank<r>``, all ranks meet at a barrier, and only then
+    rank 0 atomically replaces the marker ``<path>.latest`` = {iter, prev, world}. A job that dies while
+    some ranks are still writing leaves the marker on the previous, complete generation, which is kept
+    until the new one is committed; older generations are deleted afterwards."""
+    import json
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     payload = {
         "iter": it,
         "world": world,
+        "step_count": getattr(engine, "step_count", None),
         "optimizer": engine.optimizer_state_dict(),
         "buffers": {k: v.detach().cpu() for k, v in engine.module.named_buffers() if v is not None},
         "torch_rng": torch.get_rng_state(),
@@ -54,14 +86,65 @@ def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: in
         "loaders": loader_states if loader_states is not None else [l.state_dict() for l in loaders],
         "extra": extra or {},
     }
-    tmp = f"{path}.rank{rank}.tmp"
-    torch.save(payload, tmp)
-    os.replace(tmp, f"{path}.rank{rank}")
-    comm.barrier()
+    mine = _gen_file(path, it, rank)
+    torch.save(payload, mine + ".tmp")
+    os.replace(mine + ".tmp", mine)
+    comm.barrier()                      # every rank's file of this generation is complete
+    old = _read_marker(path)
+    prev = old[0] if old is not None and old[0] != it else (old[1] if old is not None else None)
+    if rank == 0:
+        with open(_marker(path) + ".tmp", "w") as f:
+            json.dump({"iter": it, "prev": prev, "world": world}, f)
+        os.replace(_marker(path) + ".tmp", _marker(path))
+    comm.barrier()                      # the generation is committed
+    if old is not None and old[1] is not None and old[1] not in (it, prev):
+        try:
+            os.remove(_gen_file(path, old[1], rank))
+        except OSError:
+            pass
 
 
-def load_resume(path: str, engine, loaders=(), rank: int = 0) -> int:
-    payload = torch.load(f"{path}.rank{rank}", map_location=engine.device, weights_only=False)
+def resume_candidates(path: str) -> list[int | None]:
+    """Iterations to try, newest first: the committed generation, then the one before it; a bare
+    ``<path>.rank<r>`` set (the single-generation layout of earlier versions) is tried last as None."""
+    m = _read_marker(path)
+    out: list[int | None] = []
+    if m is not None:
+        out.append(m[0])
+        if m[1] is not None:
+            out.append(m[1])
+    out.append(None)
+    return out
+
+
+def find_resume(path: str, rank: int, device) -> int | None | bool:
+    """The newest generation whose file exists on EVERY rank: its iteration, None for the legacy
+    single-generation layout, or False when there is nothing to resume from. Collective."""
+    for it in resume_candidates(path):
+        f = f"{path}.rank{rank}" if it is None else _gen_file(path, it, rank)
+        if _all_ranks(os.path.exists(f), device):
+            return it
+    return False
+
+
+def load_resume(path: str, engine, loaders=(), rank: int = 0, generation: int | None | bool = False) -> int:
+    """Load this rank's file of ``generation`` (default: the newest one complete on every rank) and check
+    that all ranks resume from the same iteration and optimizer step: ranks restarting from different
+    iterations would silently diverge (replicas) or stitch shards of different steps into one model."""
+    if generation is False:
+        generation = find_resume(path, rank, engine.device)
+        if generation is False:
+            raise FileNotFoundError(f"no complete resume generation under {path}")
+    fname = f"{path}.rank{rank}" if generation is None else _gen_file(path, generation, rank)
+    payload = torch.load(fname, map_location=engine.device, weights_only=False)
+    key = torch.tensor([float(payload["iter"]), float(payload.get("step_count") or 0)], dtype=torch.float64,
+                       device=engine.device)
+    lo, hi = key.clone(), key.clone()
+    comm.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    comm.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"resume files under {path} disagree across ranks: iteration / optimizer step "
+                           f"{lo.tolist()} .. {hi.tolist()}; refusing to resume from a mixed set")
     engine.load_optimizer_state_dict(payload["optimizer"])
     with torch.no_grad():
         bufs = dict(engine.module.named_buffers())

@@ -85,6 +85,9 @@ class Engine(nn.Module):
         self._max_norm = 0.0
         self._norm2 = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._have_norm = False
+        # optimizer steps the AdamW kernel skipped because the gradient norm was not finite (device-side
+        # count: the skip itself happens on the device, the host never looks at the norm)
+        self._skipped = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._dyn = None   # device {lr, bc1, bc2_sqrt} while a captured step is recorded / replayed (parallel/graph.py)
         self._sync_initial_state()
         self._build_storage()
@@ -217,9 +220,17 @@ class Engine(nn.Module):
         if not self._have_norm:
             self._compute_norm()   # also provides the overflow check
         self.step_count += 1
+        self._skipped += torch.isfinite(self._norm2).logical_not()
         self._apply_updates(float(lr))
         self._have_norm = False
         self._post_step()
+
+    def skipped_steps(self) -> int:
+        """Number of optimizer steps skipped so far for a non-finite gradient norm (reads the device:
+        call it where the host synchronises anyway, e.g. when it reads the loss). The step counter that
+        drives Adam's bias corrections keeps counting skipped steps: after t updates and s skips the
+        corrections are those of step t + s, which only matters for the first few hundred steps."""
+        return int(self._skipped.item())
 
     def _apply_updates(self, lr: float):
         for g, o in zip(self.groups, self.optims):

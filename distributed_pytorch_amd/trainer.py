@@ -138,9 +138,8 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         # restart-friendly: continue from this run's own periodic resume files if every rank has one
         # (torchrun --max-restarts relaunches the same command line after a failure), else start fresh
         cand = tc.file_name + "_resume"
-        have = torch.tensor([1.0 if os.path.exists(f"{cand}.rank{info.rank}") else 0.0], device=device)
-        comm.all_reduce(have, op=torch.distributed.ReduceOp.MIN)
-        resume_path = cand if have.item() > 0 else ""
+        from .checkpoint import find_resume
+        resume_path = cand if find_resume(cand, info.rank, device) is not False else ""
         say(f"--resume auto: {'found ' + cand if resume_path else 'no resume files, starting fresh'}")
     if resume_path:
         start_iter = load_resume(resume_path, engine, (train_loader, val_loader), info.rank) + 1
@@ -166,6 +165,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
     train_loss_stats, valrun_val, valrun_train = [], [], []
     x, y = train_loader.next_batch()
     last_loss = float("nan")
+    n_skipped = 0
     tokens_per_s = 0.0
     # Fault injection for restart drills: DPA_FAULT_AT_ITER=<n> makes the last rank die once at iteration n
     # (a marker file keeps the relaunched job from dying again).
@@ -221,6 +221,11 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         if read_loss:
             last_loss = loss.item() * grad_accum_steps   # the only host<-device sync of the step
             train_loss_stats.append(last_loss)
+            skipped = engine.skipped_steps()
+            if skipped > n_skipped:
+                say(f"warning: {skipped - n_skipped} optimizer step(s) skipped for a non-finite gradient norm "
+                    f"({skipped} so far)")
+                n_skipped = skipped
         mem = 0
         if device.type == "cuda":
             if read_loss:

@@ -101,3 +101,32 @@ def test_synthetic_data_is_rebuilt_for_another_vocabulary(tmp_path):
     small = np.fromfile(os.path.join(d, "train.bin"), dtype=np.uint16)
     assert small.max() < 65 and len(small) == 20000
     check_vocab(os.path.join(d, "train.bin"), 65)
+
+
+def test_skipped_steps_are_counted():
+    """A non-finite gradient norm skips the update; the engine counts it instead of hiding it."""
+    import torch
+    from distributed_pytorch_amd.config import LLMconfig
+    from distributed_pytorch_amd.models.llm import LLM
+    from distributed_pytorch_amd.parallel.engine import Engine
+    torch.manual_seed(0)
+    cfg = LLMconfig(vocab_size=64, block_size=8, n_embd=16, n_layer=1, n_head=2, up_dim=32, attn="mha",
+                    pos_emb="learn", non_linearity="gelu").finalize()
+    eng = Engine(LLM(cfg), dtype="fp32")
+    x = torch.randint(0, 64, (2, 8))
+    before = [o.master.clone() for o in eng.optims]
+    eng.zero_grad()
+    _, loss, _ = eng(x, x.roll(-1, dims=1))
+    loss.backward()
+    eng.groups[0].grad[0] = float("inf")
+    eng.clip_grad_norm_(1.0)
+    eng.step(1e-2)
+    assert eng.skipped_steps() == 1
+    assert all(torch.equal(a, o.master) for a, o in zip(before, eng.optims))
+    eng.zero_grad()
+    _, loss, _ = eng(x, x.roll(-1, dims=1))
+    loss.backward()
+    eng.clip_grad_norm_(1.0)
+    eng.step(1e-2)
+    assert eng.skipped_steps() == 1
+    assert not torch.equal(before[0], eng.optims[0].master)

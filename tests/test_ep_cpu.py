@@ -127,3 +127,28 @@ def test_ep_with_fsdp_dense_matches_single(aux_free):
     assert list(got.keys()) == list(sd.keys())
     for k in sd:
         assert torch.allclose(got[k].float(), sd[k].float(), rtol=2e-4, atol=2e-5), f"{k} differs after the step"
+
+
+def _overlap_worker(rank, world):
+    from distributed_pytorch_amd.parallel.ep import EPEngine
+    model, cfg = _make(False)
+    eng = EPEngine(model, weight_decay=0.0, dtype="fp32", eps=1e-5, bucket_mb=0.01)
+    assert eng._n_dense_groups >= 2 and len(eng.groups) == eng._n_dense_groups + 1
+    xb = _batch(cfg, 4)
+    x = xb[rank * 2:(rank + 1) * 2]
+    eng.zero_grad()
+    _, loss, _ = eng(x, x.roll(-1, 1))
+    loss.backward()
+    # the dense buckets were all-reduced from the gradient hooks, during backward: all launched, the
+    # work handles are waiting, and finish_grad_sync has nothing left to issue
+    launched_in_backward = sum(eng._launched[: eng._n_dense_groups])
+    n_works = len(eng._works)
+    eng.finish_grad_sync()
+    return launched_in_backward, n_works, eng._n_dense_groups
+
+
+def test_ep_dense_buckets_leave_during_backward():
+    """The expert group has no gradient hooks; it must not hold back the last-to-first launch order of
+    the dense buckets (which would serialise every all-reduce behind the backward pass)."""
+    for launched, n_works, n_dense in run_distributed(_overlap_worker, 2):
+        assert launched == n_dense and n_works == n_dense

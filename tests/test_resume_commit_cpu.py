@@ -1,0 +1,81 @@
+"""Resume points are committed as a set: per-rank files of one iteration, a barrier, then one marker.
+A rank that died while saving must never make the job resume from a mixed set of iterations."""
+import os
+import shutil
+
+import pytest
+import torch
+
+from dist_utils import run_distributed
+
+from distributed_pytorch_amd.checkpoint import _gen_file, _read_marker, find_resume, load_resume, save_resume
+from distributed_pytorch_amd.config import LLMconfig
+from distributed_pytorch_amd.models.llm import LLM
+
+CFG = dict(vocab_size=128, block_size=16, n_embd=32, n_layer=2, n_head=2, up_dim=64, attn="mha", pos_emb="learn",
+           non_linearity="gelu")
+
+
+def _engine(mode):
+    torch.manual_seed(0)
+    model = LLM(LLMconfig(**CFG).finalize())
+    kw = dict(weight_decay=0.1, dtype="fp32", bucket_mb=0.01)
+    if mode == "zero2":
+        from distributed_pytorch_amd.parallel.zero import ZeroEngine
+        return ZeroEngine(model, stage=2, **kw)
+    from distributed_pytorch_amd.parallel.ddp import DDPEngine
+    return DDPEngine(model, **kw)
+
+
+def _step(eng, rank, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, CFG["vocab_size"], (4, CFG["block_size"]), generator=g)[rank * 2:(rank + 1) * 2]
+    eng.zero_grad()
+    _, loss, _ = eng(x, x.roll(-1, dims=1))
+    loss.backward()
+    eng.clip_grad_norm_(1.0)
+    eng.step(1e-2)
+
+
+def _worker(rank, world, root, mode, scenario):
+    path = os.path.join(root, "run_resume")
+    eng = _engine(mode)
+    for it in range(3):
+        _step(eng, rank, it)
+        save_resume(path, eng, it, (), rank, world)
+    assert _read_marker(path) == (2, 1)
+    # generations 2 and 1 are on disk, generation 0 is gone
+    assert os.path.exists(_gen_file(path, 2, rank)) and os.path.exists(_gen_file(path, 1, rank))
+    assert not os.path.exists(_gen_file(path, 0, rank))
+    torch.distributed.barrier()
+    if scenario == "lost_file":
+        # one rank's file of the committed generation is lost: every rank falls back to the one before
+        if rank == 1:
+            os.remove(_gen_file(path, 2, rank))
+        torch.distributed.barrier()
+        assert find_resume(path, rank, eng.device) == 1
+        fresh = _engine(mode)
+        assert load_resume(path, fresh, (), rank) == 1
+        return True
+    if scenario == "mixed":
+        # one rank's file is replaced by an older iteration's (what independent per-rank replacement used
+        # to produce when a rank died mid-save): loading must refuse, not silently diverge
+        if rank == 1:
+            shutil.copy(_gen_file(path, 1, rank), _gen_file(path, 2, rank))
+        torch.distributed.barrier()
+        fresh = _engine(mode)
+        with pytest.raises(RuntimeError, match="disagree across ranks"):
+            load_resume(path, fresh, (), rank)
+        return True
+    # intact: the newest generation loads and restores the optimizer shards exactly
+    fresh = _engine(mode)
+    assert load_resume(path, fresh, (), rank) == 2
+    for a, b in zip(eng.optims, fresh.optims):
+        assert torch.equal(a.master, b.master) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    assert fresh.step_count == eng.step_count
+    return True
+
+
+@pytest.mark.parametrize("scenario", ["intact", "lost_file", "mixed"])
+def test_resume_generations_are_committed_as_a_set(tmp_path, scenario):
+    assert all(run_distributed(_worker, 2, str(tmp_path), "zero2" if scenario != "mixed" else "ddp", scenario))
