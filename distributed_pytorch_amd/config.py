@@ -109,7 +109,7 @@ class Trainconfig:
     resume: str = ""                  # resume checkpoint written with --save_interval; "auto" = this run's own, if present
     save_interval: int = 0
     metrics_jsonl: str = ""
-    profile: bool = False
+    profile: str = ""                 # "" off | events (no synchronisation) | sync | kernels (per-kernel table)
     log_interval: int = 1
     sync_loss_every: int = 1          # host reads the loss every N steps (1 = reference behaviour)
     hip_graph: str = "auto"           # whole optimizer step replayed from one hipGraph: auto | on | off
@@ -231,7 +231,9 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--resume", type=str, default=tc.resume)
     p.add_argument("--save_interval", type=int, default=tc.save_interval)
     p.add_argument("--metrics_jsonl", type=str, default=tc.metrics_jsonl)
-    p.add_argument("--profile", action="store_true")
+    p.add_argument("--profile", type=str, nargs="?", const="events", default=tc.profile,
+                   choices=["", "events", "sync", "kernels"],
+                   help="phase timing from stream events (default), synchronised wall clock, or a per-kernel table")
     p.add_argument("--log_interval", type=int, default=tc.log_interval)
     p.add_argument("--sync_loss_every", type=int, default=tc.sync_loss_every)
     p.add_argument("--hip_graph", type=str, nargs="?", const="on", default=tc.hip_graph, choices=["auto", "on", "off"],

@@ -156,6 +156,12 @@ def _count(kind: str, t: torch.Tensor):
     STATS[kind] += t.numel() * t.element_size()
 
 
+def _prof(kind: str, t: torch.Tensor):
+    """roctx range ``comm_issue:<kind>`` + host enqueue time + bytes of one collective (--profile)."""
+    from ..utils.profiling import comm_range
+    return comm_range(kind, t.numel() * t.element_size())
+
+
 def _staged(t: torch.Tensor, group) -> bool:
     """gloo with GPU tensors (several ranks rehearsing on one GPU): the transport runs on a host copy,
     synchronously. gloo's own device-tensor path does not complete on this ROCm stack."""
@@ -171,7 +177,8 @@ def all_reduce(t: torch.Tensor, op=None, group=None, async_op: bool = False):
         dist.all_reduce(h, op=op or dist.ReduceOp.SUM, group=group)
         t.copy_(h)
         return _Done()
-    w = dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=async_op)
+    with _prof("all_reduce", t):
+        w = dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=group, async_op=async_op)
     return w if async_op else _Done()
 
 
@@ -184,7 +191,8 @@ def broadcast(t: torch.Tensor, src: int = 0, group=None, async_op: bool = False)
         dist.broadcast(h, src=src, group=group)
         t.copy_(h)
         return _Done()
-    w = dist.broadcast(t, src=src, group=group, async_op=async_op)
+    with _prof("broadcast", t):
+        w = dist.broadcast(t, src=src, group=group, async_op=async_op)
     return w if async_op else _Done()
 
 
@@ -204,7 +212,8 @@ def reduce_scatter(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: b
         r = get_rank(group)
         out.copy_(tmp[r * n:(r + 1) * n])
         return _Done()
-    w = dist.reduce_scatter_tensor(out, inp, group=group, async_op=async_op)
+    with _prof("reduce_scatter", inp):
+        w = dist.reduce_scatter_tensor(out, inp, group=group, async_op=async_op)
     return w if async_op else _Done()
 
 
@@ -225,7 +234,8 @@ def all_gather(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool 
         for r, p in enumerate(parts):
             out[r * n:(r + 1) * n].copy_(p)
         return _Done()
-    w = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+    with _prof("all_gather", out):
+        w = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
     return w if async_op else _Done()
 
 
@@ -249,7 +259,8 @@ def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=
             rows.append(peer_rows[start:start + peer_splits[r]])
         out.copy_(torch.cat(rows, 0))
         return _Done()
-    w = dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+    with _prof("all_to_all", inp):
+        w = dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
     return w if async_op else _Done()
 
 

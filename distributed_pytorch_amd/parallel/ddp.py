@@ -103,8 +103,10 @@ class DDPEngine(Engine):
             for gi in reversed(range(len(self.groups))):
                 if not self._launched[gi]:
                     self._launch(gi)
-        for w in self._works:
-            w.wait()
+        from ..utils.profiling import comm_wait_range
+        with comm_wait_range():       # communication that backward did not hide
+            for w in self._works:
+                w.wait()
         self._works = []
 
     def zero_grad(self, set_to_none: bool = True):

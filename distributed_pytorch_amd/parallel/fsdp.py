@@ -39,6 +39,14 @@ from .engine import Engine
 from .flat import FlatAdamW, FlatGroup, plan_groups
 
 
+def _debug_streams() -> bool:
+    """DPA_DEBUG_STREAMS=1: releasing a buffer that an unfinished collective still reads or writes is an
+    error (raised) instead of being repaired by waiting for it. The engine's call order never does that;
+    the switch proves it, and catches a change that would."""
+    import os
+    return os.environ.get("DPA_DEBUG_STREAMS", "0") == "1"
+
+
 class FSDPUnit(FlatGroup):
     """A FlatGroup whose full parameter / gradient buffers exist only while needed."""
 
@@ -55,6 +63,7 @@ class FSDPUnit(FlatGroup):
         self._nbytes = self.data.untyped_storage().nbytes()
         self.gathered = True
         self.gather_work = None
+        self.rs_work = None            # reduce-scatter reading the full gradient buffer, until waited for
         self.grad_alive = False
         self.pending = 0
 
@@ -66,6 +75,7 @@ class FSDPUnit(FlatGroup):
     # -- parameters -------------------------------------------------------------------------
     def release_params(self):
         if self.gather_work is not None:     # a prefetch nobody consumed: retire it before freeing
+            # (not an ordering error: the gather is the unit's own and nothing has read its output yet)
             self.gather_work.wait()
             self.gather_work = None
             self.gathered = True
@@ -111,6 +121,11 @@ class FSDPUnit(FlatGroup):
             super().fold()
 
     def release_grad(self):
+        if self.rs_work is not None:
+            assert not _debug_streams(), \
+                f"unit {self.name}: gradient buffer released while its reduce-scatter is still in flight"
+            self.rs_work.wait()
+            self.rs_work = None
         if self.grad_alive:
             for s in self.slots:
                 s.param.grad = None
@@ -206,12 +221,14 @@ class FSDPEngine(Engine):
         u.fold()
         w = comm.reduce_scatter(u.grad_shard, u.rgrad, group=self.group, async_op=True)
         u.reduced = True
+        u.rs_work = w
         if u is not self.root and self.reshard_after_forward:
             u.release_params()
         self._rs_inflight.append((w, u))
         while len(self._rs_inflight) > 2:   # bound the number of full gradient buffers alive
             w0, u0 = self._rs_inflight.popleft()
             w0.wait()
+            u0.rs_work = None
             u0.release_grad()
 
     # ---- step lifecycle -------------------------------------------------------------------
@@ -243,10 +260,13 @@ class FSDPEngine(Engine):
             for u in reversed(self.units):          # units whose hooks did not all fire
                 if u.grad_alive and not getattr(u, "reduced", False):
                     self._reduce_unit(u)
-        while self._rs_inflight:
-            w, u = self._rs_inflight.popleft()
-            w.wait()
-            u.release_grad()
+        from ..utils.profiling import comm_wait_range
+        with comm_wait_range():       # communication that backward did not hide
+            while self._rs_inflight:
+                w, u = self._rs_inflight.popleft()
+                w.wait()
+                u.rs_work = None
+                u.release_grad()
 
     def _grad_mul(self) -> float:
         return 1.0 / self.world

@@ -162,6 +162,9 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
 
     sink = JsonlSink(tc.metrics_jsonl if master else "")
     timer = PhaseTimer(tc.profile)
+    from .utils import profiling
+    profiling.set_active(timer if timer.enabled else None)
+    ktable = profiling.KernelTable(timer.mode == "kernels" and device.type == "cuda")
     train_loss_stats, valrun_val, valrun_train = [], [], []
     x, y = train_loader.next_batch()
     last_loss = float("nan")
@@ -193,6 +196,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
                 f"dt {1000 * (b - a):.4f}ms")
             t0 = b
 
+        ktable.step_begin()
         if graphed is not None:
             batches = [(x, y)]
             for _ in range(grad_accum_steps - 1):
@@ -217,6 +221,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
                     engine.clip_grad_norm_(tc.grad_clip)
                 optimizer.step()
 
+        ktable.step_end()
         read_loss = (it % max(tc.sync_loss_every, 1) == 0) or it == tc.max_iters
         if read_loss:
             last_loss = loss.item() * grad_accum_steps   # the only host<-device sync of the step
@@ -246,6 +251,9 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
 
     if tc.profile and master:
         print(timer.report(), flush=True)
+        if ktable.table:
+            print(ktable.table, flush=True)
+    profiling.set_active(None)
     result = {"final_loss": last_loss, "tokens_per_s": tokens_per_s, "losses": train_loss_stats,
               "grad_accum_steps": grad_accum_steps, "total_params": total, "active_params": active}
     if tc.save_model:

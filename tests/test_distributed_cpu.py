@@ -262,3 +262,42 @@ def test_fp32_gradient_accumulation_drifts_less_than_bf16():
     # both carry the bf16 forward / backward error; only the narrow one adds accumulation rounding
     assert err_wide <= err_narrow * 1.02, (err_wide, err_narrow)
     assert err_narrow < 5e-2, err_narrow
+
+
+# ---- FSDP buffer lifetime ----------------------------------------------------------------------------
+def _fsdp_lifetime_worker(rank, world):
+    import os
+    from distributed_pytorch_amd.parallel.fsdp import FSDPEngine
+    os.environ["DPA_DEBUG_STREAMS"] = "1"      # the whole test runs with the ordering assertions armed
+    model, cfg = _make("gpt", seed=0)
+    eng = FSDPEngine(model, weight_decay=0.1, dtype="fp32", bucket_mb=0.05, eps=1e-5)
+    u = eng.block_units[1]
+    assert not u.gathered
+    # a prefetch that nobody consumes (e.g. an evaluation that stops early): releasing the unit retires the
+    # gather first and leaves it in a state from which the next forward gathers again
+    u.begin_gather(eng.group)
+    assert u.gather_work is not None
+    u.release_params()
+    assert u.gather_work is None and not u.gathered and u.data.untyped_storage().nbytes() == 0
+    batches = _batches(cfg, 2, 4, 1)
+    losses = _train(eng, batches, rank, world, 1)      # full steps under the assertions: none fires
+    assert all(torch.isfinite(torch.tensor(l)) for l in losses)
+    # releasing a gradient buffer under a reduce-scatter that has not been waited for is caught
+    class _Live:
+        def wait(self):
+            return True
+    u.materialize_grad()
+    u.rs_work = _Live()
+    try:
+        u.release_grad()
+        raised = False
+    except AssertionError:
+        raised = True
+    u.rs_work = None
+    u.release_grad()
+    os.environ.pop("DPA_DEBUG_STREAMS")
+    return raised
+
+
+def test_fsdp_unconsumed_prefetch_and_release_ordering():
+    assert all(run_distributed(_fsdp_lifetime_worker, 2))

@@ -877,3 +877,28 @@ def test_mlp_gelu_fused_fwd_bwd():
     assert rel_err(x.grad, xr.grad) < 8e-3
     assert rel_err(w1.grad, w1r.grad) < 8e-3
     assert rel_err(w2.grad, w2r.grad) < 8e-3
+
+
+@pytest.mark.parametrize("with_bias", [False, True])
+@pytest.mark.parametrize("acc_dtype", [torch.bfloat16, torch.float32])
+def test_wgrad2_direct_accumulates_into_nonzero_flat_views(with_bias, acc_dtype):
+    """The hot-path weight-gradient op: dW (and the bias gradient) are ADDED into views of a flat
+    gradient buffer that already holds a previous micro-step's gradient."""
+    torch.manual_seed(7)
+    M, N, K = 4096, 768, 768
+    dy = torch.randn(M, N, device=DEV).bfloat16()
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    flat = (torch.randn(N * K + N + 64, device=DEV) * 5).to(acc_dtype)
+    before = flat.clone()
+    dw_view = flat[: N * K].view(N, K)
+    db_view = flat[N * K: N * K + N] if with_bias else None
+    _ops().wgrad2_direct(dy, x, dw_view, db_view)
+    want_w = before[: N * K].float().view(N, K) + dy.float().t() @ x.float()
+    tol = 1e-2 if acc_dtype == torch.bfloat16 else 4e-3
+    assert rel_err(dw_view, want_w) < tol
+    if with_bias:
+        want_b = before[N * K: N * K + N].float() + dy.float().sum(0)
+        assert rel_err(db_view, want_b) < tol
+    else:
+        assert torch.equal(flat[N * K:], before[N * K:])   # nothing beyond the weight view is touched
+    assert torch.equal(flat[N * K + N:], before[N * K + N:])

@@ -52,12 +52,15 @@ def test_bf16_hip_matches_fp32_eager(name):
     _, got, _ = eng(idx.cuda(), tgt.cuda())
     got.backward()
     assert abs(got.item() - want.item()) < 3e-2 * abs(want.item())
-    # gradient direction agrees (bf16 vs fp32): cosine similarity over the big tensors
+    # every big gradient tensor agrees with the fp32 model to bf16 accuracy: relative L2 error per tensor
+    worst = (0.0, "")
     for n, p in eng.module.named_parameters():
         if p.numel() >= 4096 and "gate" not in n:
             a, b = p.grad.float().flatten().cpu(), gref[n].flatten()
-            cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
-            assert cos > 0.98, f"{name}: grad of {n} diverges (cos {cos:.4f})"
+            err = ((a - b).norm() / (b.norm() + 1e-12)).item()
+            worst = max(worst, (err, n))
+            assert err < 3e-2, f"{name}: grad of {n} is off by {err:.4f} (relative L2)"
+    print(f"{name}: worst relative gradient error {worst[0]:.4f} ({worst[1]})")
 
 
 @pytest.mark.parametrize("mode", ["single", "ddp", "zero1", "zero2", "fsdp"])
