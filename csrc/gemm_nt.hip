@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "host_logic.h"
 #include "kernels.h"
 
 namespace dpa {
@@ -46,7 +47,7 @@ constexpr int kStoreAux = DPA_GEMM_STORE_AUX;   // cache policy bits of the epil
 constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
 constexpr int kCopy = 4 * kUnit;        // a K-tile: Am0, Am1, Bn0, Bn1
 constexpr int kBiasLds = 2 * kCopy;     // fp32 bias staged behind the two copies
-constexpr int kMaxBiasN = 8192;
+constexpr int kMaxBiasN = kGemmNtMaxBiasN;
 constexpr int kLds = kBiasLds + kMaxBiasN * 4;   // 160 KiB
 
 __device__ __forceinline__ f32x4 mfma16(bfrag8 a, bfrag8 b, f32x4 c) {
@@ -103,10 +104,6 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) 
   dact = fmaf(x * e, 0.3989422804f, phi);
 }
 
-struct TileCoord {
-  int m0, n0;
-};
-
 // vmcnt immediates of the four phases of a K-tile, and whether phases 0 and 1 issue a unit refill
 template <int W0, int W1, int W2, int W3, bool ISSUE01>
 struct KtCfg {
@@ -115,49 +112,6 @@ struct KtCfg {
 };
 
 }  // namespace
-
-// Tile walk. Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the m-tiles are
-// split into 8 contiguous ranges, one per XCD label (blockIdx % 8), and inside a range the tiles that
-// run at the same time form blocks of 4 m-tiles x all n-tiles, so that concurrent workgroups of an
-// XCD share A and B panels through that L2. Any (blockIdx, iteration) -> tile bijection is correct;
-// this one is for locality.
-struct GemmWalk {
-  int tiles_m, tiles_n, nwg;
-  __device__ __forceinline__ bool xcd_mode() const { return tiles_m >= 8 && (nwg & 7) == 0; }
-  __device__ __forceinline__ int count(int wg) const {
-    if (!xcd_mode()) {
-      const int total = tiles_m * tiles_n;
-      return wg < total ? (total - wg + nwg - 1) / nwg : 0;
-    }
-    const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
-    const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
-    const int total = (hi - lo) * tiles_n;
-    return slot < total ? (total - slot + per - 1) / per : 0;
-  }
-  __device__ __forceinline__ TileCoord at(int wg, int it) const {
-    TileCoord t;
-    if (!xcd_mode()) {
-      const int s = wg + it * nwg;
-      t.m0 = (s % tiles_m) * 256;
-      t.n0 = (s / tiles_m) * 256;
-      return t;
-    }
-    const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
-    const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
-    const int s = slot + it * per;
-    const int gsz = 4 * tiles_n;
-    const int nfull = (hi - lo) / 4;
-    int g = s / gsz, r = s % gsz, gm = 4;
-    if (g >= nfull) {
-      g = nfull;
-      r = s - nfull * gsz;
-      gm = (hi - lo) - 4 * nfull;
-    }
-    t.n0 = (r / gm) * 256;
-    t.m0 = (lo + 4 * g + r % gm) * 256;
-    return t;
-  }
-};
 
 // ABL (timing-only ablations, results wrong): 1 = no LDS-DMA in the K-loop, 2 = no fragment reads, 4 = no
 // barriers, 8 = no MFMAs.
@@ -562,14 +516,7 @@ void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st) {
 
 bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
                 bool has_bias) {
-  const long long lim = 0x80000000ll;   // offsets at or above 2 GiB are the "outside every buffer" range
-  if (M < 1 || N < 16 || K < 128 || K % 64 != 0 || N % 16 != 0) return false;
-  if (lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ld_aux % 8 != 0) return false;
-  if (lda < K || ldb < K || ldc < N || (ld_aux != 0 && ld_aux < N)) return false;
-  if (M * lda * 2 >= lim || N * ldb * 2 >= lim || M * ldc * 2 >= lim || M * ld_aux * 2 >= lim) return false;
-  if (256 * lda * 2 >= (1ll << 30) || 256 * ldb * 2 >= (1ll << 30)) return false;
-  if (has_bias && N > kMaxBiasN) return false;
-  return true;
+  return gemm_nt_shape_ok(M, N, K, lda, ldb, ldc, ld_aux, has_bias);
 }
 
 int g_gemm_nt_variant = 0;   // benchmark knob: bit 0 = one barrier per phase, bit 1 = drop the stores (timing only)
@@ -585,11 +532,7 @@ void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   a.aux_bytes = (unsigned)(((long long)a.M - 1) * a.ld_aux * 2 + (long long)a.N * 2);
   if (g_gemm_nt_variant & 2) a.c_bytes = a.aux_bytes = 0;
   a.skew_ticks = (g_gemm_nt_variant >> 8);
-  const int total = a.tiles_m * a.tiles_n;
-  int grid = num_cus > 0 ? num_cus : 256;
-  grid &= ~7;
-  if (grid < 8) grid = 8;
-  if (a.tiles_m < 8 && grid > total) grid = total;
+  const int grid = gemm_nt_grid(a.tiles_m, a.tiles_n, num_cus);
   static bool attr = false;
 #define DPA_GNT_ALL(F)                                                                  \
   F(kEpiNone, false) F(kEpiNone, true) F(kEpiGelu, false) F(kEpiGelu, true) F(kEpiMul, false) F(kEpiMul, true) \

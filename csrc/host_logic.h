@@ -1,0 +1,88 @@
+// Host-checkable logic shared by the kernels and their launchers: shape admission rules and the
+// persistent tile walk. Plain C++ (no HIP headers) so that the same code also builds with g++ under
+// AddressSanitizer / UBSan in tests/native/.
+#pragma once
+
+#if defined(__HIPCC__)
+#define DPA_HD __host__ __device__ __forceinline__
+#else
+#define DPA_HD inline
+#endif
+
+namespace dpa {
+
+constexpr int kGemmNtMaxBiasN = 8192;   // fp32 bias row kept in LDS: 32 KiB
+
+struct TileCoord {
+  int m0, n0;
+};
+
+// Tile walk of the persistent NT GEMM. Workgroups are dealt round-robin to the 8 XCDs (each with its
+// own L2): the m-tiles are split into 8 contiguous ranges, one per XCD label (blockIdx % 8), and inside
+// a range the tiles that run at the same time form blocks of 4 m-tiles x all n-tiles, so that
+// concurrent workgroups of an XCD share A and B panels through that L2. Any (blockIdx, iteration) ->
+// tile bijection is correct; this one is for locality.
+struct GemmWalk {
+  int tiles_m, tiles_n, nwg;
+  DPA_HD bool xcd_mode() const { return tiles_m >= 8 && (nwg & 7) == 0; }
+  DPA_HD int count(int wg) const {
+    if (!xcd_mode()) {
+      const int total = tiles_m * tiles_n;
+      return wg < total ? (total - wg + nwg - 1) / nwg : 0;
+    }
+    const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
+    const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
+    const int total = (hi - lo) * tiles_n;
+    return slot < total ? (total - slot + per - 1) / per : 0;
+  }
+  DPA_HD TileCoord at(int wg, int it) const {
+    TileCoord t;
+    if (!xcd_mode()) {
+      const int s = wg + it * nwg;
+      t.m0 = (s % tiles_m) * 256;
+      t.n0 = (s / tiles_m) * 256;
+      return t;
+    }
+    const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
+    const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
+    const int s = slot + it * per;
+    const int gsz = 4 * tiles_n;
+    const int nfull = (hi - lo) / 4;
+    int g = s / gsz, r = s % gsz, gm = 4;
+    if (g >= nfull) {
+      g = nfull;
+      r = s - nfull * gsz;
+      gm = (hi - lo) - 4 * nfull;
+    }
+    t.n0 = (r / gm) * 256;
+    t.m0 = (lo + 4 * g + r % gm) * 256;
+    return t;
+  }
+};
+
+// Number of workgroups the NT GEMM launches for a tile grid on a part with `num_cus` compute units.
+inline int gemm_nt_grid(int tiles_m, int tiles_n, int num_cus) {
+  const int total = tiles_m * tiles_n;
+  int grid = num_cus > 0 ? num_cus : 256;
+  grid &= ~7;
+  if (grid < 8) grid = 8;
+  if (tiles_m < 8 && grid > total) grid = total;
+  return grid;
+}
+
+// Shapes the NT GEMM accepts. Every byte offset the kernel forms must stay below 2 GiB: offsets at or
+// above that are its "outside every buffer" range, used to turn loads into zeros and stores into no-ops.
+inline bool gemm_nt_shape_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
+                             long long ld_aux, bool has_bias) {
+  const long long lim = 0x80000000ll;
+  if (M < 1 || N < 16 || K < 128 || K % 64 != 0 || N % 16 != 0) return false;
+  if (lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ld_aux % 8 != 0) return false;
+  if (lda < K || ldb < K || ldc < N || (ld_aux != 0 && ld_aux < N)) return false;
+  if (M >= lim || N >= lim || lda >= lim || ldb >= lim || ldc >= lim || ld_aux >= lim) return false;
+  if (M * lda * 2 >= lim || N * ldb * 2 >= lim || M * ldc * 2 >= lim || M * ld_aux * 2 >= lim) return false;
+  if (256 * lda * 2 >= (1ll << 30) || 256 * ldb * 2 >= (1ll << 30)) return false;
+  if (has_bias && N > kGemmNtMaxBiasN) return false;
+  return true;
+}
+
+}  // namespace dpa
