@@ -58,8 +58,10 @@ def main():
                     help="dtype of the flat gradient buffers and of the gradient collectives")
     ap.add_argument("--rccl_max_channels", type=int, default=0, help="NCCL_MAX_NCHANNELS for RCCL (0: leave alone)")
     ap.add_argument("--rccl_min_channels", type=int, default=0, help="NCCL_MIN_NCHANNELS for RCCL (0: leave alone)")
-    ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high"],
-                    help="priority of the HIP stream the collectives run on")
+    ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high", "low"],
+                    help="priority of the HIP stream the collectives run on (low: own communicator only)")
+    ap.add_argument("--comm_backend", type=str, default="c10d", choices=["c10d", "own"],
+                    help="GPU transport: c10d's ProcessGroupNCCL (RCCL) or the framework's own RCCL communicator")
     args = ap.parse_args()
 
     # stdout carries exactly one line (the JSON result): everything else that native libraries print
@@ -72,7 +74,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py measures on the GPU"
     comm.configure_rccl_env(max_channels=args.rccl_max_channels, min_channels=args.rccl_min_channels,
-                            stream_priority=args.comm_priority)
+                            stream_priority=args.comm_priority, backend=args.comm_backend)
     dist_job = world > 1 or comm.FORCE_COLLECTIVES   # DPA_FORCE_DIST=1: rehearse the RCCL paths with one rank
     mode = args.mode if dist_job else ("single" if args.mode == "ddp" else args.mode)
     info = comm.init_distributed() if dist_job else comm.DistInfo(0, 0, 1, torch.device("cuda:0"), "none")
@@ -142,6 +144,8 @@ def main():
         ones = torch.ones(1, dtype=torch.float32, device=info.device)
         comm.all_reduce(ones)
         rccl_ranks = int(round(ones.item()))
+        if comm.own_comm() is not None:
+            assert comm.own_comm().comm_count() == rccl_ranks
     for k in comm.STATS:
         comm.STATS[k] = 0
     # Timed region: exactly args.steps steps between two (barrier + device synchronize) pairs; the whole

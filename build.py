@@ -79,7 +79,8 @@ def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
                 (ROOT / "build" / "asm").mkdir(parents=True, exist_ok=True)
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
             jobs.append(cmd)
-    for bsrc in sorted(CSRC.glob("*.cpp")):      # translation units that include PyTorch headers
+    # translation units that include PyTorch headers (csrc/comm: the RCCL layer)
+    for bsrc in sorted(CSRC.glob("*.cpp")) + sorted((CSRC / "comm").glob("*.cpp")):
         bobj = OBJ / (bsrc.stem + ".o")
         objs.append(bobj)
         if force or _stale(bsrc, bobj, headers):
@@ -96,6 +97,7 @@ def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
     if jobs or not OUT.exists() or force:
         link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(OUT), *map(str, objs),
                 f"-L{torch_lib}", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip",
+                "-lrccl",   # PyTorch's own copy (same soname as the system one): one RCCL per process
                 f"-Wl,-rpath,{torch_lib}"]
         _run(link)
         if verbose:

@@ -102,7 +102,8 @@ class Trainconfig:
     bucket_mb: float = 48.0           # gradient bucket size for DDP / ZeRO
     rccl_max_channels: int = 0        # NCCL_MAX_NCHANNELS of the RCCL communicator (0: RCCL's choice)
     rccl_min_channels: int = 0        # NCCL_MIN_NCHANNELS (0: RCCL's choice)
-    comm_priority: str = "default"    # priority of the stream the collectives run on: default | high
+    comm_priority: str = "default"    # priority of the stream the collectives run on: default | high | low (own)
+    comm_backend: str = "c10d"        # GPU transport: c10d (ProcessGroupNCCL = RCCL) | own (csrc/comm communicator)
     data_dir: str = ""                # overrides ../data/<dataset>
     synthetic_tokens: int = 0         # >0: generate a synthetic uint16 token stream of that length
     seed: int = 1729
@@ -224,7 +225,8 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--bucket_mb", type=float, default=tc.bucket_mb)
     p.add_argument("--rccl_max_channels", type=int, default=tc.rccl_max_channels)
     p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels)
-    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high"])
+    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high", "low"])
+    p.add_argument("--comm_backend", type=str, default=tc.comm_backend, choices=["c10d", "own"])
     p.add_argument("--data_dir", type=str, default=tc.data_dir)
     p.add_argument("--synthetic_tokens", type=str, default=str(tc.synthetic_tokens))
     p.add_argument("--seed", type=int, default=tc.seed)

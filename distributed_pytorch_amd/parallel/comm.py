@@ -1,10 +1,17 @@
-"""Process-group bootstrap and thin collective wrappers.
+"""Process-group bootstrap and the collective entry points of the framework.
 
 One process per GPU, launched by ``torchrun`` (env ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` /
-``MASTER_ADDR`` / ``MASTER_PORT``). On the GPU the backend is ``nccl`` — which on ROCm *is* RCCL
-over xGMI; on the CPU (plumbing tests) it is ``gloo``. Every collective of the framework goes
-through this module, operates on large flat buffers and is asynchronous by default, so it is
-the single place to count bytes, switch backends, or tune RCCL.
+``MASTER_ADDR`` / ``MASTER_PORT``). Every collective of the framework goes through this module,
+operates on large flat buffers and is asynchronous by default, so it is the single place to count
+bytes, switch backends, or tune RCCL. Three transports sit behind the same functions:
+
+* ``nccl``  — c10d's ProcessGroupNCCL, which on ROCm *is* RCCL over xGMI (the default on the GPU);
+* ``rccl``  — the framework's own communicator (csrc/comm/rccl_comm.cpp): an ``ncclComm_t`` created
+  from a unique id that rank 0 publishes over a small gloo group, its own HIP stream with an explicit
+  priority (high / default / low), per-communicator channel bounds, buffer registration and
+  per-collective device timings. GPU tensors take this path; host tensors and Python objects
+  (checkpoint bookkeeping) use the gloo group that bootstrapped it;
+* ``gloo``  — CPU plumbing tests, and several ranks rehearsing on one GPU.
 
 The reference never calls a collective itself: DDP's reducer, ``ZeroRedundancyOptimizer`` and
 FSDP issue them implicitly (reference: multi-gpu/ddp/train.py:19-36; kaggle-zero1.py:1062-1077;
@@ -48,10 +55,13 @@ class DistInfo:
         return self.rank == 0
 
 
-_SETTINGS = {"stream_priority": "default"}
+_SETTINGS = {"stream_priority": "default", "backend": None, "min_ctas": 0, "max_ctas": 0}
+_OWN = None          # torch.classes.dpa.RcclComm of the default group when the backend is "rccl"
+_PRIORITIES = {"high": -1, "default": 0, "low": 1}
 
 
-def configure_rccl_env(max_channels: int = 0, min_channels: int = 0, stream_priority: str | None = None):
+def configure_rccl_env(max_channels: int = 0, min_channels: int = 0, stream_priority: str | None = None,
+                       backend: str | None = None):
     """Environment of the RCCL communicator; call before ``init_distributed``.
 
     ``max_channels`` / ``min_channels`` (> 0) bound the number of RCCL channels, i.e. of workgroups
@@ -59,7 +69,10 @@ def configure_rccl_env(max_channels: int = 0, min_channels: int = 0, stream_prio
     channels per peer saturates the links, and every channel beyond that only takes CUs away from the
     MFMA kernels. ``stream_priority`` ("default" | "high") is the priority of the HIP stream the
     collectives run on (high: a ready collective's kernel is scheduled ahead of queued compute
-    kernels, so a bucket leaves as soon as it is complete)."""
+    kernels, so a bucket leaves as soon as it is complete; "low", own communicator only: collectives
+    only fill gaps the compute stream leaves). ``backend`` ("nccl" | "rccl" | "gloo") selects the
+    transport, see the module docstring; with "rccl" the channel bounds are also given to that one
+    communicator as its CTA bounds instead of to every communicator of the process."""
     # dmabuf IPC is the only mode the host driver supports on this pool.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # Keep the rendezvous on the loopback interface: container hostnames may not resolve.
@@ -68,9 +81,13 @@ def configure_rccl_env(max_channels: int = 0, min_channels: int = 0, stream_prio
         os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))
     if min_channels > 0:
         os.environ["NCCL_MIN_NCHANNELS"] = str(int(min_channels))
+    _SETTINGS["max_ctas"], _SETTINGS["min_ctas"] = max(int(max_channels), 0), max(int(min_channels), 0)
     if stream_priority is not None:
-        assert stream_priority in ("default", "high"), stream_priority
+        assert stream_priority in _PRIORITIES, stream_priority
         _SETTINGS["stream_priority"] = stream_priority
+    if backend is not None:
+        assert backend in ("nccl", "rccl", "gloo", "c10d", "own"), backend
+        _SETTINGS["backend"] = {"c10d": "nccl", "own": "rccl"}.get(backend, backend)
 
 
 def rccl_settings() -> dict:
@@ -78,6 +95,8 @@ def rccl_settings() -> dict:
     return {"NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
             "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
             "stream_priority": _SETTINGS["stream_priority"],
+            "backend": "rccl(own)" if _OWN is not None else (_backend() if dist.is_initialized() else "none"),
+            "rccl_version": _OWN.rccl_version() if _OWN is not None else None,
             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
 
@@ -99,7 +118,8 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
     use_cuda = torch.cuda.is_available()
     # DPA_BACKEND=gloo lets several ranks share one GPU (rehearsal of the GPU code paths of the
     # engines on a single-GPU box; RCCL itself refuses two ranks on one device).
-    backend = backend or os.environ.get("DPA_BACKEND") or None
+    backend = backend or os.environ.get("DPA_BACKEND") or _SETTINGS["backend"] or None
+    backend = {"c10d": "nccl", "own": "rccl"}.get(backend, backend)
     ndev = torch.cuda.device_count() if use_cuda else 0
     device = torch.device(f"cuda:{local_rank % ndev}") if use_cuda else torch.device("cpu")
     if use_cuda:
@@ -108,8 +128,12 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
         return DistInfo(0, 0, 1, device, "none")
     configure_rccl_env()
     backend = backend or ("nccl" if use_cuda else "gloo")
+    if backend == "rccl" and not use_cuda:
+        backend = "gloo"
     if not dist.is_initialized():
-        kwargs = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        # the own communicator is bootstrapped (and host-side objects are exchanged) over a gloo group
+        kwargs = dict(backend="gloo" if backend == "rccl" else backend, rank=rank, world_size=world,
+                      timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
             kwargs["device_id"] = device
             if _SETTINGS["stream_priority"] == "high":
@@ -123,12 +147,96 @@ def init_distributed(backend: str | None = None, timeout_s: int = 600) -> DistIn
             base, _, _ = next(dist.rendezvous("env://", rank, world, timeout=kwargs["timeout"]))
             kwargs["store"] = dist.PrefixStore(f"dpa_attempt_{restart}", base)
         dist.init_process_group(**kwargs)
+    if backend == "rccl":
+        _create_own(rank, world, device)
     return DistInfo(rank, local_rank, world, device, backend)
 
 
+def _create_own(rank: int, world: int, device: torch.device):
+    """Rank 0 draws the unique id, everyone receives it over gloo, every rank joins the communicator."""
+    global _OWN
+    if _OWN is not None:
+        return
+    from .. import _ext
+    assert _ext.available(), "the own RCCL communicator lives in the HIP extension (python build.py)"
+    cls = torch.classes.dpa.RcclComm
+    if _SETTINGS["stream_priority"] == "high" and os.environ.get("DPA_OWN_HIGH_PRIORITY", "0") != "1":
+        # Measured on ROCm 7.0.2 / RCCL 2.26.6 (benchmarks/debug/prio_loop.py): RCCL calls issued directly on
+        # a high-priority stream stop completing after the fourth one, with every rank count and with or
+        # without channel bounds; the same event chain without RCCL, and c10d's high-priority option, run.
+        raise ValueError("--comm_priority high stalls under the own RCCL communicator on this ROCm stack; use "
+                         "--comm_backend c10d for a high-priority stream (DPA_OWN_HIGH_PRIORITY=1 overrides)")
+    uid = cls.unique_id() if rank == 0 else torch.zeros(128, dtype=torch.uint8)
+    dist.broadcast(uid, src=0)
+    _OWN = cls(uid, rank, world, device.index or 0, _PRIORITIES[_SETTINGS["stream_priority"]],
+               _SETTINGS["min_ctas"], _SETTINGS["max_ctas"])
+    seen = _OWN.comm_count()
+    assert seen == world, f"RCCL reports {seen} ranks in the communicator, the launcher {world}"
+
+
+def own_comm():
+    """The framework-owned RCCL communicator of the default group (None on the c10d / gloo transports)."""
+    return _OWN
+
+
+def register_buffer(t: torch.Tensor) -> bool:
+    """Register a persistent flat buffer with the own communicator (no-op elsewhere)."""
+    return bool(_OWN.register_buffer(t)) if _OWN is not None and t.is_cuda else False
+
+
+def set_comm_timing(on: bool):
+    """Device-side start/stop events around every collective of the own communicator."""
+    if _OWN is not None:
+        _OWN.set_timing(bool(on))
+
+
+def drain_comm_timings():
+    """[(kind, bytes, ms on the communication stream)] of the finished collectives since the last call."""
+    return list(_OWN.drain_timings()) if _OWN is not None else []
+
+
+def check_comm_health():
+    """Raise if RCCL has recorded an asynchronous error on the own communicator (a peer died, a link
+    failed): called at the logging points of the training loop so that a broken job stops instead of hanging."""
+    if _OWN is not None:
+        err = _OWN.async_error()
+        if err:
+            raise RuntimeError(f"RCCL communicator error: {err}")
+
+
 def shutdown():
+    global _OWN
+    if _OWN is not None:
+        _OWN.destroy()
+        _OWN = None
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+_OPS = {}
+
+
+def _own_op(op) -> int:
+    if not _OPS:
+        R = dist.ReduceOp
+        _OPS.update({R.SUM: 0, R.PRODUCT: 1, R.MAX: 2, R.MIN: 3, R.AVG: 4})
+    return 0 if op is None else _OPS[op]
+
+
+def _use_own(t: torch.Tensor, group) -> bool:
+    if _OWN is None or not t.is_cuda:
+        return False
+    assert group is None, "the own RCCL communicator spans the default group only"
+    return True
+
+
+def _own_done(work, async_op: bool):
+    """Synchronous collectives order the caller's stream behind the collective on the device (the host
+    does not block), as c10d's do."""
+    if async_op:
+        return work
+    work.wait()
+    return _Done()
 
 
 def world_size(group=None) -> int:
@@ -172,6 +280,9 @@ def all_reduce(t: torch.Tensor, op=None, group=None, async_op: bool = False):
     if _single(group):
         return _Done()
     _count("all_reduce", t)
+    if _use_own(t, group):
+        with _prof("all_reduce", t):
+            return _own_done(_OWN.all_reduce(t, _own_op(op)), async_op)
     if _staged(t, group):
         h = t.float().cpu() if t.dtype == torch.bfloat16 else t.cpu()
         dist.all_reduce(h, op=op or dist.ReduceOp.SUM, group=group)
@@ -186,6 +297,9 @@ def broadcast(t: torch.Tensor, src: int = 0, group=None, async_op: bool = False)
     if _single(group):
         return _Done()
     _count("broadcast", t)
+    if _use_own(t, group):
+        with _prof("broadcast", t):
+            return _own_done(_OWN.broadcast(t, src), async_op)
     if _staged(t, group):
         h = t.cpu()
         dist.broadcast(h, src=src, group=group)
@@ -204,6 +318,9 @@ def reduce_scatter(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: b
             out.copy_(inp)
         return _Done()
     _count("reduce_scatter", inp)
+    if _use_own(inp, group):
+        with _prof("reduce_scatter", inp):
+            return _own_done(_OWN.reduce_scatter(out, inp, 0), async_op)
     if _backend(group) == "gloo":
         # gloo has no reduce-scatter: sum everything, keep the local slice (tests only)
         tmp = inp.float().cpu() if inp.is_cuda else inp.clone()
@@ -226,6 +343,9 @@ def all_gather(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool 
             out.copy_(inp)
         return _Done()
     _count("all_gather", out)
+    if _use_own(out, group):
+        with _prof("all_gather", out):
+            return _own_done(_OWN.all_gather(out, inp), async_op)
     if _backend(group) == "gloo":
         n = inp.numel()
         src = inp.cpu() if inp.is_cuda else inp.clone()
@@ -246,6 +366,11 @@ def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=
         out.copy_(inp)
         return _Done()
     _count("all_to_all", inp)
+    if _use_own(inp, group):
+        with _prof("all_to_all", inp):
+            w = _OWN.all_to_all(out, inp, [int(v) for v in out_splits] if out_splits is not None else [],
+                                [int(v) for v in in_splits] if in_splits is not None else [])
+            return _own_done(w, async_op)
     if _staged(inp, group):
         # gloo has no all-to-all on device tensors: gather every rank's rows on the host, keep ours
         W, r = world_size(group), get_rank(group)
@@ -266,4 +391,6 @@ def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=
 
 def barrier(group=None):
     if not _single(group):
+        if _OWN is not None and group is None:
+            _OWN.barrier()      # through the GPUs: also proves the communicator is alive
         dist.barrier(group=group)

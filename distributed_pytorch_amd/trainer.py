@@ -88,7 +88,8 @@ def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
 
 def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
     if mode != "single":
-        comm.configure_rccl_env(tc.rccl_max_channels, tc.rccl_min_channels, tc.comm_priority)
+        comm.configure_rccl_env(tc.rccl_max_channels, tc.rccl_min_channels, tc.comm_priority,
+                                backend=tc.comm_backend if torch.cuda.is_available() else None)
     info = comm.init_distributed() if mode != "single" else comm.DistInfo(
         0, 0, 1, torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu"), "none")
     master = info.is_master
@@ -226,6 +227,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         if read_loss:
             last_loss = loss.item() * grad_accum_steps   # the only host<-device sync of the step
             train_loss_stats.append(last_loss)
+            comm.check_comm_health()
             skipped = engine.skipped_steps()
             if skipped > n_skipped:
                 say(f"warning: {skipped - n_skipped} optimizer step(s) skipped for a non-finite gradient norm "

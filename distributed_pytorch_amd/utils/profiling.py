@@ -121,7 +121,25 @@ class PhaseTimer:
         for k, v in sorted(self.host.items(), key=lambda kv: -kv[1]):
             mb = self.bytes[k] / 2 ** 20
             lines.append(f"{k:<24} {self.cnt[k]:>6} {1000 * v:>11.2f}   (host enqueue time, {mb:,.1f} MiB moved)")
+        lines += self._comm_busy_lines()
         return "\n".join(lines)
+
+    @staticmethod
+    def _comm_busy_lines():
+        """Device time of each collective on the communication stream (own RCCL communicator only):
+        together with ``comm_wait`` it tells how much of the communication ran hidden under compute."""
+        from ..parallel import comm
+        busy, nbytes, calls = {}, {}, {}
+        for kind, b, ms in comm.drain_comm_timings():
+            busy[kind] = busy.get(kind, 0.0) + ms
+            nbytes[kind] = nbytes.get(kind, 0) + b
+            calls[kind] = calls.get(kind, 0) + 1
+        out = []
+        for k, ms in sorted(busy.items(), key=lambda kv: -kv[1]):
+            gbs = nbytes[k] / 1e9 / (ms * 1e-3) if ms > 0 else 0.0
+            out.append(f"{'comm_busy:' + k:<24} {calls[k]:>6} {ms:>11.2f}   (on the communication stream, "
+                       f"{nbytes[k] / 2 ** 20:,.1f} MiB, {gbs:,.1f} GB/s)")
+        return out
 
 
 # The timer the communication layer reports to (set by the trainer for the duration of a --profile run).
@@ -131,6 +149,8 @@ _active: PhaseTimer | None = None
 def set_active(timer: PhaseTimer | None):
     global _active
     _active = timer
+    from ..parallel import comm
+    comm.set_comm_timing(timer is not None and timer.enabled)
 
 
 def comm_range(kind: str, nbytes: int = 0):

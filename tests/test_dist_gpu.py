@@ -113,21 +113,27 @@ def test_vocab_parallel_cross_entropy_hip_halves(one_rank_group):
     assert err.item() < 1e-2
 
 
-@pytest.mark.parametrize("mode", ["ddp", "fsdp"])
-def test_bench_launch_line_prints_one_json_line(mode):
-    """The multi-GPU launch line with one rank: stdout is exactly the JSON result."""
+@pytest.mark.parametrize("mode,backend", [("ddp", "c10d"), ("fsdp", "c10d"), ("ddp", "own"), ("zero2", "own")])
+def test_bench_launch_line_prints_one_json_line(mode, backend):
+    """The multi-GPU launch line with one rank: stdout is exactly the JSON result, with the pinned
+    protocol's statistics and the fields a scaling record is cross-checked against."""
     env = dict(os.environ, DPA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29579", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "1", "--batch", "4", "--mode", mode]
+           "--warmup", "1", "--batch", "4", "--mode", mode, "--comm_backend", backend]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config"):
+                "vs_baseline", "dtype", "data", "config", "baseline_source", "step_ms", "tokens_per_sec_median_step",
+                "rccl_ranks", "comm_bytes_per_step", "n_buckets", "grad_dtype", "rccl_env"):
         assert key in out
+    assert set(out["step_ms"]) == {"median", "mean", "p10", "p90"}
+    assert out["step_ms"]["p10"] <= out["step_ms"]["median"] <= out["step_ms"]["p90"]
+    assert out["rccl_ranks"] == 1 and out["n_buckets"] >= 1 and sum(out["comm_bytes_per_step"].values()) > 0
+    assert out["rccl_env"]["backend"] == ("rccl(own)" if backend == "own" else "nccl")
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["seq_len"] == 1024 and out["config"]["global_batch"] == 4
 
