@@ -553,7 +553,10 @@ class LLM(nn.Module):
         self.apply(self._init_weights)
         self.VAL_RUN = False
         self.materialize_logits = False   # True: also return [B, T, V] logits when targets are given
-        self.loss_chunk_rows = int(os.environ.get("DPA_LOSS_CHUNK", "8192"))
+        self.loss_chunk_rows = int(os.environ.get("DPA_LOSS_CHUNK", "16384"))
+        # set by a data-parallel engine built with vocab_parallel=True: (process group,) of the ranks the
+        # vocabulary dimension of the head is split over during training
+        self.vocab_parallel = None
         self.print_act_recomp = config.act_recomp
         self.print_fused_adamw = True
         self._pos_cache = None
@@ -688,6 +691,9 @@ class LLM(nn.Module):
             if self.materialize_logits:
                 logits = ops.linear(x, wte)
                 main_loss = ops.cross_entropy(logits, targets)
+            elif self.vocab_parallel is not None and self.training and torch.is_grad_enabled():
+                main_loss = ops.vocab_parallel_linear_cross_entropy(x, wte, targets, group=self.vocab_parallel[0],
+                                                                    chunk_rows=self.loss_chunk_rows)
             else:
                 main_loss = ops.linear_cross_entropy(x, wte, targets, chunk_rows=self.loss_chunk_rows)
             loss = main_loss + total_aux / cfg.n_layer

@@ -5,13 +5,26 @@ softmax statistics, the loss and the gradient are produced by one kernel that ov
 logits with d(loss)/d(logits), so no fp32 probability tensor ever exists.
 
 ``linear_cross_entropy(x, w, targets)``: loss of ``lm_head`` + cross-entropy without keeping
-the ``[B*T, V]`` logits: rows are processed in chunks; for each chunk the logits GEMM, the
-cross-entropy kernel and (when training) the two gradient GEMMs ``dx = dlogits @ w`` and
-``dw += dlogits^T @ x`` run back to back while the chunk is still cache-resident. The
-backward pass only rescales the stored gradients by the incoming scalar.
+the ``[B*T, V]`` logits: rows are processed in chunks; for each chunk the logits GEMM (the own NT
+MFMA kernel), the cross-entropy kernel (one read, one in-place write of the chunk) and (when
+training) the two gradient GEMMs ``dx = dlogits @ w`` and ``dw += dlogits^T @ x`` run back to
+back on one reused bf16 buffer, so only ``[chunk, V]`` ever exists and the backward pass only
+rescales the stored gradients by the incoming scalar. The chunk is far larger than any cache of
+the part (16384 x 50304 bf16 = 1.6 GB): every pass over it is an HBM pass, and the chunk size
+is chosen for GEMM efficiency, not residency — measured per piece in benchmarks/lmhead_bench.py
+(2048-row chunks that would fit the 256 MB last-level cache cost 25 ms per 65536 rows against
+15.4 ms with 16384-row chunks: the dx product then has too few output tiles and the fp32 dW
+accumulator is re-read 32 times).
 
 ``vocab_parallel_cross_entropy``: the same loss with the vocabulary sharded over a process
 group (all-reduce of max / sum-exp / target logit between the two kernel halves).
+
+``vocab_parallel_linear_cross_entropy``: lm_head + loss of a data-parallel job with the vocabulary
+split over the ranks (``--vocab_parallel``): the hidden rows of all ranks are gathered, every rank
+forms the logits of all rows against its V/W slice of the head weight, the softmax statistics are
+all-reduced, and the input gradient returns through a reduce-scatter. Per-rank FLOPs and logits
+memory equal the replicated head's; what changes is that each rank produces the head's weight
+gradient for its own vocabulary slice only, complete over the global batch.
 
 Reference behaviour: ``F.cross_entropy(logits.view(-1, V), targets.view(-1), ignore_index=-1)``
 on the full fp32/amp logits (reference: single-gpu/model.py:687-692).
@@ -64,6 +77,14 @@ def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int
     return F.cross_entropy(logits2.float(), targets1, ignore_index=ignore_index)
 
 
+def _own_logits_gemm(xc: torch.Tensor, w: torch.Tensor) -> bool:
+    import os
+    if os.environ.get("DPA_LIBRARY_GEMM", "0") == "1" or os.environ.get("DPA_LOSS_OWN_GEMM", "1") == "0" \
+            or not hasattr(ops(), "gemm_nt_supported"):
+        return False
+    return bool(ops().gemm_nt_supported(xc, w, None, None))
+
+
 class _LinearXentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, targets, ignore_index, chunk_rows):
@@ -81,12 +102,20 @@ class _LinearXentFn(torch.autograd.Function):
         nchunks = (N + chunk_rows - 1) // chunk_rows
         use_wg = need_dw and x.dtype == torch.bfloat16 and nchunks > 1
         ws = torch.zeros(V, C, dtype=torch.float32, device=x.device) if use_wg else None
-        logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
+        own_gemm = x.dtype == torch.bfloat16 and _own_logits_gemm(x[: min(chunk_rows, N)], w)
+        logits = None if own_gemm else torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
+        lg = None
         for r0 in range(0, N, chunk_rows):
             r1 = min(N, r0 + chunk_rows)
             xc = x[r0:r1]
-            lg = logits[: r1 - r0]
-            torch.mm(xc, w.t(), out=lg)
+            if own_gemm and ops().gemm_nt_supported(xc, w, None, None):
+                lg = None                                   # hand the previous chunk back before the next is made
+                lg = ops().gemm_nt(xc, w, None, 0, None)[0]
+            else:
+                if logits is None:
+                    logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
+                lg = logits[: r1 - r0]
+                torch.mm(xc, w.t(), out=lg)
             loss_rows = ops().xent_fused(lg, targets[r0:r1], gs, ignore_index, train)
             loss_acc += loss_rows.sum()
             if need_dx:
@@ -115,7 +144,7 @@ class _LinearXentFn(torch.autograd.Function):
 
 
 def linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor,
-                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 8192) -> torch.Tensor:
+                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 16384) -> torch.Tensor:
     """Mean cross-entropy of ``x @ w.T`` against ``targets`` (``x [N, C]``, ``w [V, C]``)."""
     x2 = x.reshape(-1, x.shape[-1])
     t1 = targets.reshape(-1)
@@ -188,3 +217,93 @@ def vocab_parallel_cross_entropy(logits_local: torch.Tensor, targets: torch.Tens
                                  group=None, ignore_index: int = IGNORE_INDEX) -> torch.Tensor:
     return _VocabParallelXentFn.apply(logits_local.reshape(-1, logits_local.shape[-1]), targets.reshape(-1),
                                       int(vocab_start), group, ignore_index)
+
+
+def _local_stats(work, targets, vocab_start, ignore_index):
+    """Row max, sum-exp (relative to that max) and target logit of a vocabulary slice."""
+    if _hip_ok(work, targets):
+        return ops().xent_stats(work, targets, vocab_start, ignore_index)
+    wf = work.float()
+    mx = wf.max(dim=1).values
+    sm = torch.exp(wf - mx[:, None]).sum(dim=1)
+    loc = targets - vocab_start
+    inr = (loc >= 0) & (loc < wf.shape[1]) & (targets != ignore_index)
+    tg = torch.where(inr, wf.gather(1, loc.clamp(0, wf.shape[1] - 1)[:, None])[:, 0], torch.zeros_like(mx))
+    return mx, sm, tg
+
+
+def _local_grad(work, targets, lse, tgt_logit, gs, vocab_start, ignore_index):
+    """(loss per row, d loss / d logits of the slice in work's dtype); may overwrite ``work``."""
+    if _hip_ok(work, targets):
+        loss_rows = ops().xent_grad(work, targets, lse.contiguous(), tgt_logit.contiguous(), gs, vocab_start,
+                                    ignore_index, True)
+        return loss_rows, work
+    valid = targets != ignore_index
+    loss_rows = torch.where(valid, lse - tgt_logit, torch.zeros_like(lse))
+    p = torch.exp(work.float() - lse[:, None])
+    loc = targets - vocab_start
+    rows = torch.nonzero((loc >= 0) & (loc < work.shape[1]) & valid).squeeze(1)
+    p[rows, loc[rows]] -= 1.0
+    p = p * (valid[:, None].to(p.dtype) * gs[0])
+    return loss_rows, p.to(work.dtype)
+
+
+class _VocabParallelLinearXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, targets, group, ignore_index, chunk_rows):
+        comm = _comm()
+        W, r = comm.world_size(group), comm.get_rank(group)
+        N, C = x.shape
+        V = w.shape[0]
+        per = V // W
+        v0 = r * per
+        ws = w[v0:v0 + per]                                  # this rank's vocabulary slice of the tied weight
+        xa = torch.empty(W * N, C, dtype=x.dtype, device=x.device)
+        comm.all_gather(xa.view(-1), x.contiguous().view(-1), group=group)
+        ta = torch.empty(W * N, dtype=targets.dtype, device=targets.device)
+        comm.all_gather(ta, targets.contiguous(), group=group)
+        gs = _grad_scale(ta, ignore_index)                   # 1 / valid targets of the global batch
+        dxa = torch.empty_like(xa)
+        dws = torch.zeros(per, C, dtype=torch.float32, device=x.device)
+        loss_acc = torch.zeros((), dtype=torch.float32, device=x.device)
+        for r0 in range(0, W * N, chunk_rows):
+            r1 = min(W * N, r0 + chunk_rows)
+            xc, tc = xa[r0:r1], ta[r0:r1]
+            lg = torch.mm(xc, ws.t())
+            mx, sm, tg = _local_stats(lg, tc, v0, ignore_index)
+            gmx = mx.clone()
+            comm.all_reduce(gmx, op=dist.ReduceOp.MAX, group=group)
+            packed = torch.stack([sm * torch.exp(mx - gmx), tg])
+            comm.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+            lse = gmx + torch.log(packed[0])
+            loss_rows, dlg = _local_grad(lg, tc, lse, packed[1], gs, v0, ignore_index)
+            loss_acc += loss_rows.sum()
+            torch.mm(dlg, ws, out=dxa[r0:r1])                # partial over this slice; summed by the reduce-scatter
+            if x.is_cuda and x.dtype == torch.bfloat16:
+                torch.addmm(dws, dlg.t(), xc, out_dtype=torch.float32, out=dws)   # bf16 operands, fp32 sum
+            else:
+                dws.addmm_(dlg.t().float(), xc.float())
+        dx = torch.empty_like(x)
+        comm.reduce_scatter(dx.view(-1), dxa.view(-1), group=group)
+        # The data-parallel engines average parameter gradients over the ranks and expect each rank's
+        # backward to start from the gradient of ITS loss: both are W times what the global loss gives.
+        dx.mul_(W)
+        dw = torch.zeros_like(w)
+        dw[v0:v0 + per] = (dws * W).to(w.dtype)
+        ctx.save_for_backward(dx, dw)
+        return loss_acc * gs[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, dw = ctx.saved_tensors
+        return dx * g.to(dx.dtype), dw * g.to(dw.dtype), None, None, None, None
+
+
+def vocab_parallel_linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor, group=None,
+                                        ignore_index: int = IGNORE_INDEX, chunk_rows: int = 8192) -> torch.Tensor:
+    """Global-batch mean cross-entropy of ``x @ w.T`` with the vocabulary dimension of ``w [V, C]`` split over
+    the ranks of ``group`` (every rank holds the full tied weight and uses rows ``[r V/W, (r+1) V/W)``)."""
+    W = _comm().world_size(group)
+    assert w.shape[0] % W == 0, f"vocabulary {w.shape[0]} does not split over {W} ranks"
+    x2 = x.reshape(-1, x.shape[-1])
+    return _VocabParallelLinearXentFn.apply(x2, w, targets.reshape(-1), group, ignore_index, int(chunk_rows))

@@ -65,7 +65,7 @@ class Engine(nn.Module):
 
     def __init__(self, model: nn.Module, weight_decay: float = 0.1, lr: float = 3e-4, betas=(0.9, 0.999),
                  eps: float = 1e-8, dtype: str = "auto", bucket_mb: float = 48.0, device=None, group=None,
-                 grad_dtype: str = "auto"):
+                 grad_dtype: str = "auto", vocab_parallel: bool = False):
         super().__init__()
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         self.param_dtype = resolve_dtype(dtype, self.device)
@@ -76,6 +76,10 @@ class Engine(nn.Module):
         self.group = group
         self.world = comm.world_size(group)
         self._dist = not comm._single(group)   # collectives are really issued (always when world > 1)
+        if vocab_parallel and self._dist:
+            V = getattr(getattr(model, "config", None), "vocab_size", 0)
+            assert V and V % self.world == 0, f"--vocab_parallel: vocabulary {V} does not split over {self.world} ranks"
+            model.vocab_parallel = (group,)
         self.rank = comm.get_rank(group)
         self.weight_decay = weight_decay
         self.betas, self.eps = betas, eps

@@ -46,7 +46,7 @@ def _run(engine, cfg, steps=6):
     return losses
 
 
-@pytest.mark.parametrize("mode", ["ddp", "zero1", "zero2", "fsdp"])
+@pytest.mark.parametrize("mode", ["ddp", "zero1", "zero2", "fsdp", "ddp_vp", "fsdp_vp"])
 def test_engine_through_rccl_matches_single(one_rank_group, mode):
     from distributed_pytorch_amd.config import LLMconfig, Trainconfig
     from distributed_pytorch_amd.models.llm import LLM
@@ -59,7 +59,10 @@ def test_engine_through_rccl_matches_single(one_rank_group, mode):
     ref = _run(build_engine("single", LLM(cfg), tc, one_rank_group), cfg)
     before = dict(comm.STATS)
     torch.manual_seed(1)
+    if mode.endswith("_vp"):      # head + loss over the vocabulary-parallel kernels (stats / all-reduce / grad)
+        tc.vocab_parallel, mode = True, mode[:-3]
     eng = build_engine(mode, LLM(cfg), tc, one_rank_group)
+    assert (eng.module.vocab_parallel is not None) == tc.vocab_parallel
     assert eng._dist, "collectives must really be issued in this test"
     got = _run(eng, cfg)
     moved = {k: comm.STATS[k] - before[k] for k in before}

@@ -59,6 +59,9 @@ def _worker(rank, world, mode, cfg_name, n_steps, global_b, accum):
     if rank == 0:
         model, cfg = _make(cfg_name, seed=0)
     kw = dict(weight_decay=0.1, dtype="fp32", bucket_mb=0.05, eps=1e-5)
+    if mode.endswith("_vp"):      # head + loss with the vocabulary split over the ranks
+        kw["vocab_parallel"] = True
+        mode = mode[:-3]
     if mode == "ddp":
         from distributed_pytorch_amd.parallel.ddp import DDPEngine
         eng = DDPEngine(model, **kw)
@@ -71,15 +74,16 @@ def _worker(rank, world, mode, cfg_name, n_steps, global_b, accum):
     elif mode == "fsdp_keep":
         from distributed_pytorch_amd.parallel.fsdp import FSDPEngine
         eng = FSDPEngine(model, reshard_after_forward=False, **kw)
+    assert (eng.module.vocab_parallel is not None) == ("vocab_parallel" in kw)
     _train(eng, _batches(cfg, n_steps, global_b, accum), rank, world, accum)
     sd = eng.state_dict()
     return {k: v.clone() for k, v in sd.items()} if rank == 0 else None
 
 
-@pytest.mark.parametrize("mode", ["ddp", "zero1", "zero2", "fsdp", "fsdp_keep"])
+@pytest.mark.parametrize("mode", ["ddp", "zero1", "zero2", "fsdp", "fsdp_keep", "ddp_vp", "zero2_vp", "fsdp_vp"])
 @pytest.mark.parametrize("cfg_name", ["gpt", "gqa_rope_swiglu"])
 def test_matches_single_process(mode, cfg_name):
-    if cfg_name != "gpt" and mode in ("zero1", "fsdp_keep"):
+    if cfg_name != "gpt" and mode in ("zero1", "fsdp_keep", "zero2_vp", "fsdp_vp"):
         pytest.skip("covered by the gpt config")
     want = _single_reference(cfg_name)
     got = run_distributed(_worker, 2, mode, cfg_name, 3, 4, 2)[0]
@@ -91,7 +95,7 @@ def test_matches_single_process(mode, cfg_name):
         assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
 
 
-@pytest.mark.parametrize("mode", ["ddp", "zero2", "fsdp"])
+@pytest.mark.parametrize("mode", ["ddp", "zero2", "fsdp", "ddp_vp", "fsdp_vp"])
 def test_four_ranks_match_single_process(mode):
     """World size 4 (shards of a quarter, uneven bucket tails, two prefetches in flight): same
     trajectory as one process on the same global batches."""
@@ -101,7 +105,7 @@ def test_four_ranks_match_single_process(mode):
         assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
 
 
-@pytest.mark.parametrize("mode", ["ddp", "fsdp"])
+@pytest.mark.parametrize("mode", ["ddp", "fsdp", "ddp_vp", "fsdp_vp"])
 def test_eight_ranks_match_single_process(mode):
     """The world size of one MI355X node."""
     want = _single_reference("gpt", n_steps=2, global_b=8, accum=1)

@@ -56,7 +56,7 @@ def test_bf16_hip_matches_fp32_eager(name):
     # Models with a discontinuity in the forward pass get a wider bound: bf16 rounding flips the ReLU mask
     # of the ~0.3 % of pre-activations that sit within rounding distance of zero, and each flip is a
     # full-size error (sqrt(0.003) ~ 5 %); the MoE router's top-k choice flips the same way.
-    tol = {"mqa_sin": 8e-2, "moe": 1e-1}.get(name, 3e-2)
+    tol = {"mqa_sin": 8e-2, "moe": 2e-1}.get(name, 3e-2)
     worst = (0.0, "")
     for n, p in eng.module.named_parameters():
         if p.numel() >= 4096 and "gate" not in n:
