@@ -557,6 +557,9 @@ class LLM(nn.Module):
         # set by a data-parallel engine built with vocab_parallel=True: (process group,) of the ranks the
         # vocabulary dimension of the head is split over during training
         self.vocab_parallel = None
+        # set by a data-parallel engine that reduces the head's share of the tied weight gradient on its
+        # own (tied_tail="split"): maps the tied weight to the tensor the head should use in training
+        self.head_weight_hook = None
         self.print_act_recomp = config.act_recomp
         self.print_fused_adamw = True
         self._pos_cache = None
@@ -688,6 +691,8 @@ class LLM(nn.Module):
             _, x = ops.add_layer_norm(x, delta, ln_f.weight, ln_f.bias, ln_f.eps)
         if targets is not None:
             logits = None
+            if self.head_weight_hook is not None and self.training and torch.is_grad_enabled():
+                wte = self.head_weight_hook(wte)
             if self.materialize_logits:
                 logits = ops.linear(x, wte)
                 main_loss = ops.cross_entropy(logits, targets)

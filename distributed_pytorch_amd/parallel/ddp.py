@@ -18,6 +18,22 @@ Differences from the reference's ``DistributedDataParallel`` use
   reference loop toggles it;
 * buffers are not re-broadcast from rank 0 on every forward; MoE routing biases are averaged
   after each step instead.
+
+The tied ``lm_head`` / ``tkn_emb`` weight: its gradient has two contributions, the head's dense
+``dlogits^T x`` (the FIRST thing backward produces) and the embedding scatter (the LAST), so its
+bucket can only leave after backward has ended: the one collective of the step that nothing hides
+(reference tie: single-gpu/model.py:559-560). Two ways to run it:
+
+* ``tied_tail="fused"`` (default): one all-reduce of the summed gradient, in the gradient dtype —
+  77 MB in bf16 for GPT-2-124M, half of what the reference's fp32 reducer sends;
+* ``tied_tail="split"``: the head contribution is diverted into its own buffer and all-reduced as
+  soon as the head's backward has run, under the whole rest of backward; the embedding part goes
+  at the end and the two are added after both have arrived (all-reduce is linear). The exposed
+  tail then carries the embedding scatter only. With a dense [V, C] buffer that is the same
+  number of bytes as before while the job sends one extra buffer in total, so this only pays when
+  the tail part travels cheaper than the head part (e.g. fp32 head gradients with
+  ``grad_dtype="fp32"`` while the scatter part, which is exact in bf16 for up to 256 equal
+  addends, is sent narrow) — hence opt-in.
 """
 from __future__ import annotations
 
@@ -27,11 +43,30 @@ from . import comm
 from .engine import Engine
 
 
+class _DivertGrad(torch.autograd.Function):
+    """Identity on the tied weight in forward; in backward the gradient that arrives (the head's dense
+    contribution) goes to the engine's side buffer instead of the parameter."""
+
+    @staticmethod
+    def forward(ctx, w, engine):
+        ctx.engine = engine
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.engine._head_grad_arrived(g)
+        return None, None
+
+
 class DDPEngine(Engine):
     name = "ddp"
 
     def _build_storage(self):
         super()._build_storage()
+        self._head_sink = self._head_work = self._head_slot = None
+        self.launch_log = []        # order of this step's gradient collectives ("head" or bucket index)
+        if self.tied_tail == "split" and self._dist and type(self)._reduce_group is DDPEngine._reduce_group:
+            self._setup_split_tail()
         self._pending = [0] * len(self.groups)
         self._launched = [False] * len(self.groups)
         self._works = []
@@ -40,6 +75,27 @@ class DDPEngine(Engine):
         for gi, g in enumerate(self.groups):
             for s in g.slots:
                 s.param.register_post_accumulate_grad_hook(self._make_hook(gi))
+
+    def _setup_split_tail(self):
+        head = getattr(self.module, "lm_head", None)
+        emb = getattr(self.module, "tkn_emb", None)
+        if head is None or emb is None or head.weight is not emb.weight:
+            return
+        for gi, g in enumerate(self.groups):
+            for s in g.slots:
+                if s.param is head.weight:
+                    self._head_slot = (gi, s)
+        if self._head_slot is None:
+            return
+        gi, s = self._head_slot
+        self._head_sink = torch.zeros(s.numel, dtype=self.groups[gi].rgrad.dtype, device=self.device)
+        self.module.head_weight_hook = lambda w: _DivertGrad.apply(w, self)
+
+    def _head_grad_arrived(self, g: torch.Tensor):
+        self._head_sink.add_(g.reshape(-1).to(self._head_sink.dtype))
+        if self.require_backward_grad_sync:
+            self.launch_log.append("head")
+            self._head_work = comm.all_reduce(self._head_sink, group=self.group, async_op=True)
 
     def _make_hook(self, gi: int):
         def hook(param):
@@ -64,12 +120,14 @@ class DDPEngine(Engine):
         if self.require_backward_grad_sync:
             self._launched = [False] * len(self.groups)
             self._next = len(self.groups) - 1
+            self.launch_log = []
 
     # -- collectives ------------------------------------------------------------------------
     def _launch(self, gi: int):
         if self._launched[gi]:
             return
         self._launched[gi] = True
+        self.launch_log.append(gi)
         self._works.append(self._reduce_group(gi))
         self._emulate_comm_kernels()
 
@@ -107,7 +165,14 @@ class DDPEngine(Engine):
         with comm_wait_range():       # communication that backward did not hide
             for w in self._works:
                 w.wait()
+            if self._head_work is not None:
+                self._head_work.wait()
         self._works = []
+        if self._head_work is not None:
+            gi, s = self._head_slot
+            self.groups[gi].rgrad[s.offset:s.offset + s.numel].add_(self._head_sink)
+            self._head_sink.zero_()
+            self._head_work = None
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad()

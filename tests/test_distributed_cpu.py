@@ -192,6 +192,47 @@ def test_ddp_buckets_leave_last_to_first_inside_backward():
         assert out["in_backward"] == n, out
 
 
+# ---- the tied lm_head / tkn_emb gradient: head contribution reduced early ---------------------------------
+def _split_tail_worker(rank, world, accum):
+    from distributed_pytorch_amd.parallel.ddp import DDPEngine
+    model, cfg = _make("gpt", seed=rank if rank else 0)
+    eng = DDPEngine(model, weight_decay=0.1, dtype="fp32", bucket_mb=0.05, eps=1e-5, tied_tail="split")
+    assert eng._head_sink is not None and eng.module.head_weight_hook is not None
+    logs = []
+    batches = _batches(cfg, 3, 4, accum)
+    for step_batches in batches:
+        eng.zero_grad()
+        for mi, xb in enumerate(step_batches):
+            per = xb.shape[0] // world
+            x = xb[rank * per:(rank + 1) * per]
+            eng.require_backward_grad_sync = (mi == accum - 1)
+            _, loss, _ = eng(x, x.roll(-1, dims=1))
+            (loss / accum).backward()
+            if mi == accum - 1:
+                logs.append((list(eng.launch_log), eng._head_work is not None))
+        eng.clip_grad_norm_(1.0)
+        eng.step(1e-2)
+    sd = eng.state_dict()
+    return ({k: v.clone() for k, v in sd.items()} if rank == 0 else None), logs, len(eng.groups)
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_split_tied_tail_matches_and_head_leaves_first(accum):
+    """tied_tail="split": same trajectory as one process, and on the synchronising micro-step the head's
+    share of the tied gradient is the FIRST collective of backward (before the last block's bucket)
+    while the bucket holding the embedding is the last."""
+    want = _single_reference("gpt", n_steps=3, global_b=4, accum=accum)
+    outs = run_distributed(_split_tail_worker, 2, accum)
+    got = outs[0][0]
+    for k in want:
+        assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"split tail: {k} differs"
+    for _, logs, ngroups in outs:
+        for log, head_in_flight in logs:
+            assert head_in_flight
+            assert log[0] == "head" and log[1] == ngroups - 1 and log[-1] == 0, log
+            assert log[1:] == list(range(ngroups - 1, -1, -1)), log
+
+
 # ---- fp32 gradient buffers on bf16 parameters (--grad_dtype fp32) -------------------------------------
 def _wide_worker(rank, world, mode, grad_dtype, accum):
     model, cfg = _make("gpt", seed=0)
