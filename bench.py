@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--rccl_min_channels", type=int, default=0, help="NCCL_MIN_NCHANNELS for RCCL (0: leave alone)")
     ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high", "low"],
                     help="priority of the HIP stream the collectives run on (low: own communicator only)")
+    ap.add_argument("--ep_capacity", type=float, default=0.0,
+                    help="expert parallel: static per-peer capacity factor (0: exact variable all-to-all)")
+    ap.add_argument("--vocab_parallel", action="store_true", help="split the head's vocabulary over the ranks")
+    ap.add_argument("--tied_tail", type=str, default="fused", choices=["fused", "split"])
     ap.add_argument("--comm_backend", type=str, default="c10d", choices=["c10d", "own"],
                     help="GPU transport: c10d's ProcessGroupNCCL (RCCL) or the framework's own RCCL communicator")
     args = ap.parse_args()
@@ -90,7 +94,8 @@ def main():
     global_batch = B * world * args.accum
     tc = Trainconfig(dataset="synthetic", total_batch_size=global_batch * T, batch_size=B,
                      max_iters=args.steps + args.warmup, learning_rate=3e-4, warmup_steps=10, grad_clip=1.0,
-                     bucket_mb=args.bucket_mb, dtype="bf16", grad_dtype=args.grad_dtype)
+                     bucket_mb=args.bucket_mb, dtype="bf16", grad_dtype=args.grad_dtype,
+                     ep_capacity=args.ep_capacity, vocab_parallel=args.vocab_parallel, tied_tail=args.tied_tail)
 
     data_dir = ensure_synthetic(os.path.join("/tmp", f"dpa_bench_data_v{mc.vocab_size}"), 1 << 24, mc.vocab_size, info.rank)
     check_vocab(os.path.join(data_dir, "train.bin"), mc.vocab_size)

@@ -104,6 +104,7 @@ class Trainconfig:
     rccl_min_channels: int = 0        # NCCL_MIN_NCHANNELS (0: RCCL's choice)
     comm_priority: str = "default"    # priority of the stream the collectives run on: default | high | low (own)
     vocab_parallel: bool = False      # split the head's vocabulary over the data-parallel ranks (ddp / zero / fsdp)
+    ep_capacity: float = 0.0          # expert parallel: static capacity factor per peer (0 = exact, one host read / layer)
     tied_tail: str = "fused"          # tied lm_head/tkn_emb gradient: one all-reduce at the end | split (head part early)
     comm_backend: str = "c10d"        # GPU transport: c10d (ProcessGroupNCCL = RCCL) | own (csrc/comm communicator)
     data_dir: str = ""                # overrides ../data/<dataset>
@@ -229,6 +230,7 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels)
     p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high", "low"])
     p.add_argument("--vocab_parallel", action="store_true", default=tc.vocab_parallel)
+    p.add_argument("--ep_capacity", type=float, default=tc.ep_capacity)
     p.add_argument("--tied_tail", type=str, default=tc.tied_tail, choices=["fused", "split"])
     p.add_argument("--comm_backend", type=str, default=tc.comm_backend, choices=["c10d", "own"])
     p.add_argument("--data_dir", type=str, default=tc.data_dir)

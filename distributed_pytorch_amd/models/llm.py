@@ -465,13 +465,15 @@ class MoE(nn.Module):
     def forward(self, x):
         B, T, C = x.shape
         x_flat = x.reshape(-1, C)
+        topk_indices, topk_gates, aux_loss = self.route(x_flat)
+        # expert parallel: the dispatch exchange is issued first and travels while the shared experts run
+        pending = self.dispatcher.begin(self, x_flat, topk_indices, topk_gates) if self.dispatcher is not None else None
         shared_output = None
         for i in range(self.n_shared):
             o = self.experts[i](x_flat)
             shared_output = o if shared_output is None else shared_output + o
-        topk_indices, topk_gates, aux_loss = self.route(x_flat)
-        if self.dispatcher is not None:
-            routed = self.dispatcher(self, x_flat, topk_indices, topk_gates)
+        if pending is not None:
+            routed = self.dispatcher.finish(pending)
         else:
             routed = self.routed_experts_local(x_flat, topk_indices, topk_gates)
         y = routed if shared_output is None else shared_output + routed

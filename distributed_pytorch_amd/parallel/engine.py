@@ -65,8 +65,10 @@ class Engine(nn.Module):
 
     def __init__(self, model: nn.Module, weight_decay: float = 0.1, lr: float = 3e-4, betas=(0.9, 0.999),
                  eps: float = 1e-8, dtype: str = "auto", bucket_mb: float = 48.0, device=None, group=None,
-                 grad_dtype: str = "auto", vocab_parallel: bool = False, tied_tail: str = "fused"):
+                 grad_dtype: str = "auto", vocab_parallel: bool = False, tied_tail: str = "fused",
+                 ep_capacity: float = 0.0):
         super().__init__()
+        self.ep_capacity = float(ep_capacity)   # expert-parallel engines: static per-peer capacity factor (0: exact)
         assert tied_tail in ("fused", "split"), tied_tail
         self.tied_tail = tied_tail
         self.device = torch.device(device) if device is not None else next(model.parameters()).device

@@ -41,65 +41,153 @@ from .flat import FlatAdamW, FlatGroup, plan_groups, unique_named_parameters
 
 
 class _AllToAllRows(torch.autograd.Function):
+    """Row all-to-all(v). ``box`` (a list) receives the work handle when the forward exchange is issued
+    asynchronously: the caller waits on it before touching the result."""
+
     @staticmethod
-    def forward(ctx, x, in_splits, out_splits, group):
+    def forward(ctx, x, in_splits, out_splits, group, box):
         ctx.splits = (in_splits, out_splits)
         ctx.group = group
-        out = x.new_empty((sum(out_splits),) + tuple(x.shape[1:]))
-        comm.all_to_all(out, x.contiguous(), out_splits, in_splits, group=group)
+        n_out = sum(out_splits) if out_splits is not None else x.shape[0]
+        out = x.new_empty((n_out,) + tuple(x.shape[1:]))
+        w = comm.all_to_all(out, x.contiguous(), out_splits, in_splits, group=group, async_op=box is not None)
+        if box is not None:
+            box.append(w)
         return out
 
     @staticmethod
     def backward(ctx, g):
         in_splits, out_splits = ctx.splits
-        gx = g.new_empty((sum(in_splits),) + tuple(g.shape[1:]))
+        n_in = sum(in_splits) if in_splits is not None else g.shape[0]
+        gx = g.new_empty((n_in,) + tuple(g.shape[1:]))
         comm.all_to_all(gx, g.contiguous(), in_splits, out_splits, group=ctx.group)
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
-def all_to_all_rows(x, in_splits, out_splits, group=None):
-    return _AllToAllRows.apply(x, list(in_splits), list(out_splits), group)
+def all_to_all_rows(x, in_splits, out_splits, group=None, box=None):
+    """Differentiable row exchange; ``None`` splits mean equal (static) splits."""
+    return _AllToAllRows.apply(x, None if in_splits is None else list(in_splits),
+                               None if out_splits is None else list(out_splits), group, box)
 
 
 class ExpertParallelDispatcher:
-    """Callable installed as ``MoE.dispatcher``."""
+    """Installed as ``MoE.dispatcher``. Two phases, so that the layer can run its shared experts while
+    the dispatch exchange is on the links: ``begin`` routes, sorts and issues the exchange
+    asynchronously; ``finish`` waits for it, runs the local experts and brings the results back.
 
-    def __init__(self, group=None):
+    ``capacity`` = 0 (default): exact. The per-peer row counts are read back to the host once per layer
+    (they are the split sizes of a variable all-to-all) and every routed pair is served.
+    ``capacity`` = F > 0: static shapes and NO host read. Every rank sends exactly
+    ``ceil(F * pairs / W)`` rows to every peer (zero rows past the real ones); pairs beyond a peer's
+    capacity are dropped, i.e. contribute nothing for that expert, and are counted on the device in
+    ``dropped`` (``F >= W`` can never drop). The whole layer is then enqueued without the host ever
+    waiting for the GPU, which is what keeps the kernel queue full across MoE layers."""
+
+    def __init__(self, group=None, capacity: float = 0.0):
         self.group = group
         self.world = comm.world_size(group)
         self.rank = comm.get_rank(group)
+        self.capacity = float(capacity)
+        self.dropped = None        # device counter of pairs dropped by the capacity bound
 
     def local_expert_range(self, n_routed: int):
         assert n_routed % self.world == 0, "n_routed must be divisible by the expert-parallel world size"
         per = n_routed // self.world
         return self.rank * per, (self.rank + 1) * per
 
+    def dropped_pairs(self) -> int:
+        return int(self.dropped.item()) if self.dropped is not None else 0
+
     def __call__(self, moe, x_flat, topk_indices, topk_gates):
+        return self.finish(self.begin(moe, x_flat, topk_indices, topk_gates))
+
+    # ---- phase 1 --------------------------------------------------------------------------------
+    def begin(self, moe, x_flat, topk_indices, topk_gates):
         W, per = self.world, moe.n_routed // self.world
         N, k = topk_indices.shape
         # expert-sorted (== destination-rank-sorted) send order, computed on the device
         row_of_pair, counts = ops.plan_dense(topk_indices, moe.n_routed)   # counts: rows per expert (global ids)
+        xs = ops.scatter_rows(x_flat, row_of_pair, k, N * k)
+        st = dict(moe=moe, x_flat=x_flat, row_of_pair=row_of_pair, gates=topk_gates, k=k, per=per, box=[])
+        if self.capacity > 0:
+            cap = -(-int(self.capacity * N * k) // W)
+            cap = max(8, (cap + 7) // 8 * 8)
+            cnt = counts.view(W, per)
+            want = cnt.sum(1)                                            # rows each destination should get
+            seg_start = torch.cumsum(want, 0) - want
+            end = torch.cumsum(cnt, 1)
+            send_cnt = end.clamp(max=cap) - (end - cnt).clamp(max=cap)   # per (destination, expert), clipped
+            sent = send_cnt.sum(1)
+            lost = (want - sent).sum()
+            self.dropped = lost if self.dropped is None else self.dropped + lost
+            j = torch.arange(cap, device=xs.device)
+            valid = (j[None, :] < sent[:, None]).reshape(-1)
+            src = (seg_start[:, None] + j[None, :]).clamp(max=N * k - 1).reshape(-1)
+            send = xs.index_select(0, src) * valid[:, None].to(xs.dtype)
+            recv_cnt = torch.empty_like(send_cnt)
+            comm.all_to_all(recv_cnt, send_cnt.contiguous(), group=self.group)   # [src rank][local expert]
+            recv = all_to_all_rows(send, None, None, self.group, st["box"])
+            st.update(cap=cap, src=src, valid=valid, recv_cnt=recv_cnt, recv=recv, npairs=N * k)
+            return st
         recv_counts = torch.empty_like(counts)
         comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
         recv_mat = recv_counts.view(W, per)
         # the one host read of the layer: rows sent to / received from each rank (the all-to-all splits)
         counts_h, recv_h = torch.stack([counts.view(W, per).sum(1), recv_mat.sum(1)]).tolist()
-        xs = ops.scatter_rows(x_flat, row_of_pair, k, N * k)
-        recv = all_to_all_rows(xs, counts_h, recv_h, self.group)
-        # regroup the received rows (ordered by source rank, then expert) by local expert
-        R = recv.shape[0]
-        seg_expert = torch.arange(per, device=recv.device).repeat(W)        # expert id of each (src, expert) segment
-        row_expert = torch.repeat_interleave(seg_expert, recv_mat.reshape(-1), output_size=R)
+        recv = all_to_all_rows(xs, counts_h, recv_h, self.group, st["box"])
+        st.update(recv=recv, recv_mat=recv_mat, counts_h=counts_h, recv_h=recv_h)
+        return st
+
+    # ---- phase 2 --------------------------------------------------------------------------------
+    def _local_experts(self, moe, recv, row_expert, row_weight, per):
+        """Outputs of this rank's experts for the received rows (row_weight 0 marks padding rows)."""
         lo = self.rank * per
         local = [moe.experts[moe.n_shared + lo + j].expert for j in range(per)]
+        if per == 1:
+            # one expert per rank (e.g. 8 experts on the 8 GPUs of a node): everything received is for
+            # that expert, so it is one dense MLP over the rows as they arrived — no regrouping at all.
+            # Padding rows of the static-capacity exchange are masked by the sender on return.
+            return local[0](recv)
         fcs, projs = [m.c_fc.weight for m in local], [m.c_proj.weight for m in local]
         act = local[0].non_linearity
         if not (moe.training and moe.config.dropout > 0) and ops.grouped_supported(recv, fcs, projs, act):
             # grouped MFMA GEMMs over the padded expert-sorted layout: one launch per product for all
             # local experts, nothing read back to the host
-            ones = torch.ones(R, 1, dtype=recv.dtype, device=recv.device)
-            y_recv = ops.grouped_experts(recv, row_expert.view(-1, 1), ones, fcs, projs, act)
-        else:
+            return ops.grouped_experts(recv, row_expert.view(-1, 1), row_weight.view(-1, 1).to(recv.dtype), fcs,
+                                       projs, act)
+        return None
+
+    def finish(self, st):
+        moe, per, W = st["moe"], st["per"], self.world
+        for w in st["box"]:
+            w.wait()
+        recv = st["recv"]
+        R = recv.shape[0]
+        if self.capacity > 0:
+            cap = st["cap"]
+            ends = torch.cumsum(st["recv_cnt"], 1)                            # [src, per]
+            j = torch.arange(cap, device=recv.device).expand(W, cap).contiguous()
+            row_expert = torch.searchsorted(ends, j, right=True).clamp(max=per - 1).reshape(-1)
+            row_valid = (j < ends[:, -1:]).reshape(-1)
+            y_recv = self._local_experts(moe, recv, row_expert, row_valid, per)
+            if y_recv is None:                                                # eager: every expert sees every row, masked
+                lo = self.rank * per
+                y_recv = torch.zeros_like(recv)
+                for e in range(per):
+                    m = ((row_expert == e) & row_valid)[:, None].to(recv.dtype)
+                    y_recv = y_recv + moe.experts[moe.n_shared + lo + e].expert(recv) * m
+            y_back = all_to_all_rows(y_recv, None, None, self.group)
+            y_sorted = torch.zeros(st["npairs"], recv.shape[1], dtype=y_back.dtype, device=y_back.device)
+            y_sorted = y_sorted.index_add(0, st["src"], y_back * st["valid"][:, None].to(y_back.dtype))
+            return ops.gather_combine(y_sorted, st["row_of_pair"], st["gates"], st["k"]).to(st["x_flat"].dtype)
+        recv_mat = st["recv_mat"]
+        # regroup the received rows (ordered by source rank, then expert) by local expert
+        seg_expert = torch.arange(per, device=recv.device).repeat(W)        # expert id of each (src, expert) segment
+        row_expert = torch.repeat_interleave(seg_expert, recv_mat.reshape(-1), output_size=R)
+        y_recv = self._local_experts(moe, recv, row_expert, torch.ones(R, device=recv.device), per)
+        if y_recv is None:
+            lo = self.rank * per
+            local = [moe.experts[moe.n_shared + lo + j].expert for j in range(per)]
             perm = torch.argsort(row_expert, stable=True)
             per_expert = recv_mat.sum(0).tolist()
             grouped = recv[perm]
@@ -111,12 +199,12 @@ class ExpertParallelDispatcher:
             if outs:
                 y_grouped = torch.cat(outs, dim=0)
             else:
-                y_grouped = grouped.new_zeros((0, x_flat.shape[1]))
+                y_grouped = grouped.new_zeros((0, st["x_flat"].shape[1]))
                 # keep the local experts in the autograd graph so their (zero) gradients exist
                 y_grouped = y_grouped + 0.0 * sum(p.sum() for m in local for p in m.parameters())
             y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
-        y_back = all_to_all_rows(y_recv, recv_h, counts_h, self.group)
-        return ops.gather_combine(y_back, row_of_pair, topk_gates, k).to(x_flat.dtype)
+        y_back = all_to_all_rows(y_recv, st["recv_h"], st["counts_h"], self.group)
+        return ops.gather_combine(y_back, st["row_of_pair"], st["gates"], st["k"]).to(st["x_flat"].dtype)
 
 
 def _expert_index(name: str):
@@ -136,7 +224,7 @@ class EPEngine(DDPEngine):
     name = "ep"
 
     def _build_storage(self):
-        self.dispatcher = ExpertParallelDispatcher(self.group)
+        self.dispatcher = ExpertParallelDispatcher(self.group, capacity=self.ep_capacity)
         cfg = self.module.config
         assert cfg.moe, "EPEngine needs an MoE model"
         local_named = _drop_remote_experts(self, cfg)
@@ -261,7 +349,7 @@ class EPFSDPEngine(FSDPEngine):
     name = "ep_fsdp"
 
     def _build_storage(self):
-        self.dispatcher = ExpertParallelDispatcher(self.group)
+        self.dispatcher = ExpertParallelDispatcher(self.group, capacity=self.ep_capacity)
         cfg = self.module.config
         assert cfg.moe, "EPFSDPEngine needs an MoE model"
         local_named = _drop_remote_experts(self, cfg)

@@ -65,7 +65,7 @@ def estimate_loss(model, tc: Trainconfig, train_loader, val_loader):
 def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
     kw = dict(weight_decay=tc.weight_decay, lr=tc.learning_rate, dtype=tc.dtype, bucket_mb=tc.bucket_mb,
               device=info.device, grad_dtype=tc.grad_dtype, vocab_parallel=getattr(tc, "vocab_parallel", False),
-              tied_tail=getattr(tc, "tied_tail", "fused"))
+              tied_tail=getattr(tc, "tied_tail", "fused"), ep_capacity=getattr(tc, "ep_capacity", 0.0))
     if mode == "single":
         from .parallel.engine import Engine
         return Engine(model, **kw)

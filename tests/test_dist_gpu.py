@@ -75,8 +75,8 @@ def test_engine_through_rccl_matches_single(one_rank_group, mode):
         assert abs(a - b) < 2e-2 * abs(b) + 1e-3, (mode, got, ref)
 
 
-@pytest.mark.parametrize("kind", ["ep", "ep_fsdp"])
-def test_expert_parallel_through_rccl(one_rank_group, kind):
+@pytest.mark.parametrize("kind,capacity", [("ep", 0.0), ("ep_fsdp", 0.0), ("ep", 1.0)])
+def test_expert_parallel_through_rccl(one_rank_group, kind, capacity):
     from distributed_pytorch_amd.config import LLMconfig
     from distributed_pytorch_amd.models.llm import LLM
     from distributed_pytorch_amd.parallel import comm
@@ -89,7 +89,9 @@ def test_expert_parallel_through_rccl(one_rank_group, kind):
     before = comm.STATS["all_to_all"]
     torch.manual_seed(1)
     cls = EPEngine if kind == "ep" else EPFSDPEngine
-    got = _run(cls(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3), cfg)
+    eng = cls(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3, ep_capacity=capacity)
+    got = _run(eng, cfg)
+    assert eng.dispatcher.dropped_pairs() == 0
     assert comm.STATS["all_to_all"] > before
     for a, b in zip(got, ref):
         assert abs(a - b) < 3e-2 * abs(b) + 1e-3, (got, ref)

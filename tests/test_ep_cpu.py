@@ -23,11 +23,12 @@ def _batch(cfg, global_b):
     return torch.randint(0, cfg.vocab_size, (global_b, cfg.block_size), generator=g)
 
 
-def _single(aux_free):
+def _single(aux_free, parts=2):
     from distributed_pytorch_amd.parallel.engine import Engine
     model, cfg = _make(aux_free)
     eng = Engine(model, weight_decay=0.0, dtype="fp32", eps=1e-5)
     xb = _batch(cfg, 4)
+    per = 4 // parts
     # mean over the two halves == what two data-parallel ranks compute
     eng.zero_grad()
     losses = []
@@ -35,27 +36,28 @@ def _single(aux_free):
     bufs = [b for n, b in eng.module.named_buffers() if n.endswith("expert_bias")]
     init = [b.clone() for b in bufs]
     updated = []
-    for half in (xb[:2], xb[2:]):
+    for half in (xb[i * per:(i + 1) * per] for i in range(parts)):
         for b, b0 in zip(bufs, init):
             b.copy_(b0)
         _, loss, _ = eng(half, half.roll(-1, 1))
-        (loss / 2).backward()
+        (loss / parts).backward()
         losses.append(loss.item())
         updated.append([b.clone() for b in bufs])
     for i, b in enumerate(bufs):
-        b.copy_((updated[0][i] + updated[1][i]) / 2)
+        b.copy_(sum(u[i] for u in updated) / parts)
     grads = {n: p.grad.clone() for n, p in eng.module.named_parameters()}
     eng.clip_grad_norm_(1.0)
     eng.step(1e-2)
     return losses, grads, {k: v.clone() for k, v in eng.state_dict().items()}
 
 
-def _worker(rank, world, aux_free):
+def _worker(rank, world, aux_free, capacity=0.0):
     from distributed_pytorch_amd.parallel.ep import EPEngine
     model, cfg = _make(aux_free)
-    eng = EPEngine(model, weight_decay=0.0, dtype="fp32", eps=1e-5, bucket_mb=0.01)
+    eng = EPEngine(model, weight_decay=0.0, dtype="fp32", eps=1e-5, bucket_mb=0.01, ep_capacity=capacity)
     xb = _batch(cfg, 4)
-    x = xb[rank * 2:(rank + 1) * 2]
+    per = 4 // world
+    x = xb[rank * per:(rank + 1) * per]
     eng.zero_grad()
     _, loss, _ = eng(x, x.roll(-1, 1))
     loss.backward()
@@ -64,13 +66,17 @@ def _worker(rank, world, aux_free):
     eng.clip_grad_norm_(1.0)
     eng.step(1e-2)
     sd = eng.state_dict()
-    return loss.item(), grads, ({k: v.clone() for k, v in sd.items()} if rank == 0 else None)
+    return (loss.item(), grads, ({k: v.clone() for k, v in sd.items()} if rank == 0 else None),
+            eng.dispatcher.dropped_pairs())
 
 
-@pytest.mark.parametrize("aux_free", [False, True])
-def test_ep_matches_single(aux_free):
+@pytest.mark.parametrize("aux_free,capacity", [(False, 0.0), (True, 0.0), (False, 2.0), (True, 2.0)])
+def test_ep_matches_single(aux_free, capacity):
+    """capacity 0: exact variable all-to-all. capacity = world size: the static-shape exchange without any
+    host read, which can never drop a pair and must therefore give the same numbers."""
     losses, grads, sd = _single(aux_free)
-    outs = run_distributed(_worker, 2, aux_free)
+    outs = run_distributed(_worker, 2, aux_free, capacity)
+    assert all(o[3] == 0 for o in outs)
     for r in range(2):
         assert abs(outs[r][0] - losses[r]) < 1e-5
     # dense grads are identical on both ranks; expert grads live on their owner
@@ -152,3 +158,26 @@ def test_ep_dense_buckets_leave_during_backward():
     the dense buckets (which would serialise every all-reduce behind the backward pass)."""
     for launched, n_works, n_dense in run_distributed(_overlap_worker, 2):
         assert launched == n_dense and n_works == n_dense
+
+
+def test_ep_capacity_bound_drops_and_counts_pairs():
+    """A capacity below the busiest peer's load: the step still runs with static shapes, the overflow
+    pairs are dropped (as in capacity-factor MoE training) and the device counter says how many."""
+    outs = run_distributed(_worker, 2, False, 0.4)
+    assert sum(o[3] for o in outs) > 0
+    assert all(o[0] == o[0] and abs(o[0]) < 1e4 for o in outs)     # finite losses
+
+
+@pytest.mark.parametrize("capacity", [0.0, 4.0])
+def test_ep_one_expert_per_rank(capacity):
+    """Four ranks, four routed experts: every rank owns exactly one expert and runs it as a plain dense MLP
+    over whatever arrives (no regrouping). Same numbers as one process."""
+    losses, grads, sd = _single(False, parts=4)
+    outs = run_distributed(_worker, 4, False, capacity)
+    for r in range(4):
+        assert abs(outs[r][0] - losses[r]) < 1e-5 and outs[r][3] == 0
+        for n, g in outs[r][1].items():
+            assert torch.allclose(g, grads[n], rtol=1e-4, atol=1e-6), f"rank {r}: grad of {n} differs"
+    got = outs[0][2]
+    for k in sd:
+        assert torch.allclose(got[k].float(), sd[k].float(), rtol=2e-4, atol=2e-5), f"{k} differs after the step"
