@@ -163,8 +163,7 @@ class GQA(nn.Module):
         if rope is not None:
             # rotate the q and k heads (contiguous leading part of the fused projection)
             cos_t, sin_t, pos0 = rope
-            qk = ops.apply_rope(qkv[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, pos0)
-            qkv = torch.cat([qk.view(B, T, (nh + nkv) * hs), qkv[..., (nh + nkv) * hs:]], dim=-1)
+            qkv = ops.rope_qkv_(qkv, cos_t, sin_t, pos0, nh + nkv, hs)   # in place: no copy, no re-concatenation
         if isinstance(kv_cache, _StaticLayer):
             # one new token appended in place at the device-side position, attention over the filled part
             q, k, v = ops.split_qkv(qkv, nh, nkv)

@@ -203,7 +203,9 @@ class _LinearFn(torch.autograd.Function):
         ctx.b_param = b if sole_use else None
         x2 = x.reshape(-1, x.shape[-1])
         if gemm_supported(x2, w, b):
-            return ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0].view(*x.shape[:-1], w.shape[0])
+            # _unsafe_view: the freshly made GEMM output reshaped WITHOUT view tracking, so that the caller
+            # may update it in place (rotary embedding of the q / k columns) like any tensor it owns
+            return torch.ops.aten._unsafe_view(ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0], (*x.shape[:-1], w.shape[0]))
         return F.linear(x, w, b)
 
     @staticmethod

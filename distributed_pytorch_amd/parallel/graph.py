@@ -90,7 +90,10 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(graph):
+                    # thread_local: other threads of the process (the collective watchdog polling its
+                    # events, the pinned-memory loader) keep calling the runtime while this one captures;
+                    # under the default global mode such a call aborts the capture, or the process
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         self.loss = self._body(list(self.x.unbind(0)), list(self.y.unbind(0)))
                 except Exception as exc:      # something in this configuration cannot be captured
                     eng.step_count = count

@@ -902,3 +902,27 @@ def test_wgrad2_direct_accumulates_into_nonzero_flat_views(with_bias, acc_dtype)
     else:
         assert torch.equal(flat[N * K:], before[N * K:])   # nothing beyond the weight view is touched
     assert torch.equal(flat[N * K + N:], before[N * K + N:])
+
+
+def test_rope_qkv_inplace_matches_eager_and_rotates_the_gradient_back():
+    """In-place rotary embedding of the q / k heads of a fused projection: same values as the fp32 eager
+    rotation of the slice, v untouched, and the gradient of a loss on the output is the inverse rotation."""
+    from distributed_pytorch_amd.ops.rope import _rope_eager, rope_qkv_, rope_tables
+    torch.manual_seed(0)
+    B, T, nh, nkv, hs = 2, 96, 4, 2, 64
+    W = (nh + 2 * nkv) * hs
+    cos_t, sin_t = rope_tables(128, hs, device="cuda")
+    base = torch.randn(B, T, W, device="cuda")
+    x = base.bfloat16().requires_grad_()
+    qkv = x * 1.0                                    # a tensor the op may own (not a leaf)
+    out = rope_qkv_(qkv, cos_t, sin_t, 5, nh + nkv, hs)
+    assert out.data_ptr() == qkv.data_ptr()          # really in place
+    ref_in = base.bfloat16().float()
+    want_qk = _rope_eager(ref_in[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, 5, False)
+    assert torch.allclose(out[..., : (nh + nkv) * hs].float().view(B, T, nh + nkv, hs), want_qk, atol=2e-2, rtol=2e-2)
+    assert torch.equal(out[..., (nh + nkv) * hs:], base.bfloat16()[..., (nh + nkv) * hs:])
+    g = torch.randn(B, T, W, device="cuda").bfloat16()
+    out.backward(g.clone())                          # the op rotates the gradient it is handed in place
+    want_g = _rope_eager(g.float()[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, 5, True)
+    assert torch.allclose(x.grad[..., : (nh + nkv) * hs].float().view(B, T, nh + nkv, hs), want_g, atol=2e-2, rtol=2e-2)
+    assert torch.equal(x.grad[..., (nh + nkv) * hs:], g[..., (nh + nkv) * hs:])
