@@ -43,6 +43,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 #ifndef DPA_GEMM_STORE_AUX
 #define DPA_GEMM_STORE_AUX 2   // non-temporal: measured 4-6 % faster than the default policy on the K = 768 shapes
 #endif
+#ifndef DPA_GEMM_PREFETCH_A
+#define DPA_GEMM_PREFETCH_A 1   // phase 3 (no fragment reads of its own) reads half of the next K-tile's first A fragments
+#endif
+constexpr bool kPrefetchA = DPA_GEMM_PREFETCH_A != 0;
 constexpr int kStoreAux = DPA_GEMM_STORE_AUX;   // cache policy bits of the epilogue stores (1 sc0, 2 nt, 16 sc1)
 constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
 constexpr int kCopy = 4 * kUnit;        // a K-tile: Am0, Am1, Bn0, Bn1
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 
   f32x4 acc[2][4][4];
   bfrag8 af[4][2] = {}, bf0[2][2] = {}, bf1[2][2] = {};
+  bfrag8 afn[2][2] = {};   // rows 0-31 of the NEXT K-tile's first A unit, read one phase early (kPrefetchA)
 
   auto zero_acc = [&]() {
 #pragma unroll
@@ -269,10 +274,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     }
     const char* u = smem + copy * kCopy + mh * kUnit;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = (kPrefetchA && mh == 0) ? 2 : 0; mt < 4; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
         af[mt][ks] = *reinterpret_cast<const bfrag8*>(u + (ks ? aoff1 : aoff0) + mt * 2048);
+  };
+  // The memory sections of a K-tile read 12, 4, 8 and 0 fragments; with this, 8, 4, 8 and 4: the first
+  // A unit of K-tile kt + 1 has landed (and passed a barrier) by phase 3 of K-tile kt under the same waits.
+  auto prefetch_a = [&](int copy_next) {
+    if (!kPrefetchA) return;
+    if (ABL & 2) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(afn[mt][ks]));
+      return;
+    }
+    const char* u = smem + copy_next * kCopy;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        afn[mt][ks] = *reinterpret_cast<const bfrag8*>(u + (ks ? aoff1 : aoff0) + mt * 2048);
   };
   auto read_b = [&](int copy, int nh, bfrag8 (&bf)[2][2]) {
     if (ABL & 2) {
@@ -306,7 +329,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mh][mt][2 * nh + nt] = mfma16(bf[nt][ks], af[mt][ks], acc[mh][mt][2 * nh + nt]);
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mh][mt][2 * nh + nt] = mfma16(bf[nt][ks], (kPrefetchA && mh == 0 && mt < 2) ? afn[mt][ks] : af[mt][ks],
+                                            acc[mh][mt][2 * nh + nt]);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -352,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     quadrant(1, 1, bf1);
     sync_cm();
     // phase 3: (rows 64-127, columns 0-31), operands already in registers
+    prefetch_a(copy ^ 1);
     issue(TB{}, H0{}, kt + 2, copy);
     wait_vm<Cfg::kW3>();
     sync_mc();
@@ -383,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   wait_vm<12 + kStores>();
   barrier();
   if (SYNC == 0 && wr == 1) barrier();   // the second wave group runs one barrier behind the first
+  prefetch_a(0);
 
 
   int copy = 0;
