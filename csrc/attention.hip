@@ -33,7 +33,10 @@
 namespace dpa {
 
 // A wave's [32][HS] output tile, held transposed (rows = d on registers, column = lane), is
-// turned into whole rows through LDS and stored with 16-byte accesses.
+// turned into whole rows through LDS and stored with 16-byte accesses. The 16-byte chunks of a row are
+// XOR-swizzled with the row index: without it the 32 lanes of a half-wave write one bank column (row
+// stride = 128 or 256 bytes), which the bank-conflict counter showed as ~1 conflict cycle per LDS
+// instruction of the whole kernel although the main loop's patterns have none.
 template <int HS>
 __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)[HS / 32], float mul, bf16_t* out,
                                              long long ts, int row0, int nrows, int lane) {
@@ -46,14 +49,15 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
       u32x2 w;
       w[0] = pack_bf16x2(acc[dt][4 * g4] * mul, acc[dt][4 * g4 + 1] * mul);
       w[1] = pack_bf16x2(acc[dt][4 * g4 + 2] * mul, acc[dt][4 * g4 + 3] * mul);
-      *reinterpret_cast<u32x2*>(wave_lds + r * (HS * 2) + d0 * 2) = w;
+      const int chunk = (d0 >> 3) ^ (r & (HS / 8 - 1));
+      *reinterpret_cast<u32x2*>(wave_lds + r * (HS * 2) + chunk * 16 + 8 * hh) = w;
     }
   }
   constexpr int CPR = HS / 8;
 #pragma unroll
   for (int i = 0; i < 32 * CPR / 64; ++i) {
     const int id = lane + 64 * i, row = id / CPR, ch = id % CPR;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(wave_lds + row * (HS * 2) + ch * 16);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wave_lds + row * (HS * 2) + (ch ^ (row & (CPR - 1))) * 16);
     if (row0 + row < nrows) *reinterpret_cast<u32x4*>(out + (long long)(row0 + row) * ts + ch * 8) = v;
   }
 }

@@ -130,3 +130,20 @@ def test_skipped_steps_are_counted():
     eng.step(1e-2)
     assert eng.skipped_steps() == 1
     assert not torch.equal(before[0], eng.optims[0].master)
+
+
+@pytest.mark.parametrize("flag,mode", [("--profile", "events"), ("--profile sync", "sync"), ("--profile kernels", "kernels"), ("", "")])
+def test_profile_flag_and_phase_report(tmp_path, capsys, flag, mode):
+    """``--profile`` alone means the non-synchronising event mode; every mode ends with a table of the
+    forward / backward / optimizer phases (on the CPU the phases fall back to wall clock)."""
+    argv = (f"--preset char-10m --n_layer 1 --n_embd 32 --n_head 2 --up_dim 64 --block_size 16 --vocab_size 128 "
+            f"--dataset synthetic --synthetic_tokens 4000 --data_dir {tmp_path / 'd'} --batch_size 2 "
+            f"--total_batch_size_str 2*16 --max_iters 4 --warmup_steps 1 --file_name {tmp_path / 'run'} {flag}").split()
+    tc, mc = configs_from_args(argv)
+    assert tc.profile == mode
+    train(tc, mc, mode="single")
+    out = capsys.readouterr().out
+    if mode in ("events", "sync"):
+        assert "phase (" in out and "forward" in out and "backward" in out and "optimizer" in out
+    else:                                   # "kernels" prints the device's kernel table: nothing to show on the CPU
+        assert "phase (" not in out
