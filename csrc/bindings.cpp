@@ -823,14 +823,44 @@ bool gemm_nt_supported(const Tensor& a, const Tensor& b, const std::optional<Ten
                          ld_aux ? ld_aux : b.size(0), bias.has_value());
 }
 
+// The two SwiGLU forms (see kernels.h): forward b = [gate rows | up rows] -> (act [M, U], [gate | up] [M, 2U]);
+// backward b = W_proj^T [U, K], aux = [gate | up] -> [dgate | dup] [M, 2U].
+bool gemm_nt_pair_supported(const Tensor& a, const Tensor& b, int64_t epi, const std::optional<Tensor>& aux) {
+  if (!a.is_cuda() || !b.is_cuda() || a.dim() != 2 || b.dim() != 2) return false;
+  if (a.scalar_type() != at::kBFloat16 || b.scalar_type() != at::kBFloat16) return false;
+  if (a.stride(1) != 1 || b.stride(1) != 1 || a.size(1) != b.size(1) || a.size(0) < 1) return false;
+  if (reinterpret_cast<uintptr_t>(a.data_ptr()) % 16 || reinterpret_cast<uintptr_t>(b.data_ptr()) % 16) return false;
+  const bool fwd = epi == dpa::kEpiSwiglu;
+  if (fwd && b.size(0) % 2 != 0) return false;
+  const int64_t U = fwd ? b.size(0) / 2 : b.size(0);
+  int64_t ld_pair = 2 * U;
+  if (fwd != !aux.has_value()) return false;
+  if (aux.has_value()) {
+    if (!aux->is_cuda() || aux->scalar_type() != at::kBFloat16 || aux->dim() != 2 || aux->stride(1) != 1 ||
+        aux->size(0) != a.size(0) || aux->size(1) != 2 * U || reinterpret_cast<uintptr_t>(aux->data_ptr()) % 16)
+      return false;
+    ld_pair = aux->stride(0);
+  }
+  return dpa::gemm_nt_pair_ok(a.size(0), U, a.size(1), a.stride(0), b.stride(0), U, ld_pair) &&
+         dpa::gemm_nt_pair_ok(a.size(0), U, a.size(1), a.stride(0), b.stride(0), U, 2 * U);
+}
+
 std::tuple<Tensor, std::optional<Tensor>> gemm_nt(const Tensor& a, const Tensor& b, const std::optional<Tensor>& bias, int64_t epi,
                                    const std::optional<Tensor>& aux) {
-  TORCH_CHECK(epi >= 0 && epi <= 3, "gemm_nt: epilogue 0..3");
-  TORCH_CHECK((epi == dpa::kEpiMul || epi == dpa::kEpiAdd) == aux.has_value(),
-              "gemm_nt: the multiply / add epilogues (and only they) take an auxiliary operand");
-  TORCH_CHECK(gemm_nt_supported(a, b, bias, aux), "gemm_nt: unsupported operands (see gemm_nt_supported)");
-  const int64_t M = a.size(0), N = b.size(0), K = a.size(1);
-  Tensor c = at::empty({M, N}, a.options());
+  TORCH_CHECK(epi >= 0 && epi <= 5, "gemm_nt: epilogue 0..5");
+  const bool pair = epi == dpa::kEpiSwiglu || epi == dpa::kEpiDswiglu;
+  TORCH_CHECK((epi == dpa::kEpiMul || epi == dpa::kEpiAdd || epi == dpa::kEpiDswiglu) == aux.has_value(),
+              "gemm_nt: the multiply / add / dSwiGLU epilogues (and only they) take an auxiliary operand");
+  if (pair) {
+    TORCH_CHECK(!bias.has_value(), "gemm_nt: the SwiGLU epilogues take no bias");
+    TORCH_CHECK(gemm_nt_pair_supported(a, b, epi, aux), "gemm_nt: unsupported operands (see gemm_nt_pair_supported)");
+  } else {
+    TORCH_CHECK(gemm_nt_supported(a, b, bias, aux), "gemm_nt: unsupported operands (see gemm_nt_supported)");
+  }
+  const int64_t M = a.size(0), K = a.size(1);
+  const int64_t N = epi == dpa::kEpiSwiglu ? b.size(0) / 2 : b.size(0);   // output columns before pairing (U for both SwiGLU forms)
+  const int64_t c_cols = epi == dpa::kEpiDswiglu ? 2 * N : N;
+  Tensor c = at::empty({M, c_cols}, a.options());
   std::optional<Tensor> aux_out;
   dpa::GemmNtArgs g{};
   g.a = a.data_ptr();
@@ -842,11 +872,15 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt(const Tensor& a, const Tensor&
   g.K = (int)K;
   g.lda = a.stride(0);
   g.ldb = b.stride(0);
-  g.ldc = N;
+  g.ldc = c_cols;
   g.ld_aux = N;
   if (epi == dpa::kEpiGelu) {
     aux_out = at::empty({M, N}, a.options());
     g.aux_out = aux_out->data_ptr();
+  } else if (epi == dpa::kEpiSwiglu) {
+    aux_out = at::empty({M, 2 * N}, a.options());
+    g.aux_out = aux_out->data_ptr();
+    g.ld_aux = 2 * N;
   } else if (aux.has_value()) {
     g.aux_in = aux->data_ptr();
     g.ld_aux = aux->stride(0);
@@ -867,6 +901,7 @@ Tensor transpose_bf16(const Tensor& x) {
 TORCH_LIBRARY(dpa, m) {
   m.def("gemm_nt(Tensor a, Tensor b, Tensor? bias, int epi, Tensor? aux) -> (Tensor, Tensor?)");
   m.def("gemm_nt_supported(Tensor a, Tensor b, Tensor? bias, Tensor? aux) -> bool");
+  m.def("gemm_nt_pair_supported(Tensor a, Tensor b, int epi, Tensor? aux) -> bool");
   m.def("gemm_nt_set_variant(int v) -> ()");
   m.def("transpose_bf16(Tensor x) -> Tensor");
   m.def("ws_to_many(Tensor ws, Tensor dst_ptrs, bool accumulate, bool out_bf16) -> ()");
@@ -921,6 +956,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
   m.impl("wgrad2_set_stages", [](int64_t s) { dpa::wgrad2_set_stages((int)s); });
   m.impl("gemm_nt_set_variant", [](int64_t v) { dpa::gemm_nt_set_variant((int)v); });
   m.impl("gemm_nt_supported", gemm_nt_supported);
+  m.impl("gemm_nt_pair_supported", gemm_nt_pair_supported);
 }
 
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {

@@ -121,6 +121,7 @@ struct KtCfg {
 // barriers, 8 = no MFMAs.
 template <int EPI, bool BIAS, int SYNC, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
+  constexpr bool kPair = EPI == kEpiSwiglu;   // output tile = 128 gate columns paired with their 128 up columns
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       va = (unsigned)rowA * (unsigned)p.lda * 2u + chunk * 16;
       // B unit Bn{nh}: unit row rho = 32 wc + 16 nt + i <-> tile column 64 wc + 16 (i >> 2) + 4 (2 nh + nt) + (i & 3)
       const int i = rho & 15, nt = (rho >> 4) & 1, wcs = rho >> 5;
-      const int colB = 64 * wcs + 16 * (i >> 2) + 4 * nt + (i & 3);
+      // paired (SwiGLU) tiles: a lane's columns 0-7 are gate columns, 8-15 the matching up columns (unit
+      // Bn1 = the same rows of the up half of the weight), so 32 output columns per wave column
+      const int colB = kPair ? 32 * wcs + 8 * (i >> 2) + 4 * nt + (i & 3) : 64 * wcs + 16 * (i >> 2) + 4 * nt + (i & 3);
       vb = (unsigned)colB * (unsigned)p.ldb * 2u + chunk * 16;
       pl = lds0 + pc * 1024;
     };
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     pieceLds1 = __builtin_amdgcn_readfirstlane(pieceLds1);
   }
   const unsigned aStepMh = 64u * (unsigned)p.lda * 2u;   // Am1 rows = Am0 rows + 64
-  const unsigned bStepNh = 8u * (unsigned)p.ldb * 2u;    // Bn1 columns = Bn0 columns + 8
+  // Bn1 columns = Bn0 columns + 8; paired tiles: Bn1 = the up rows, N weight rows after the gate rows
+  const unsigned bStepNh = (kPair ? (unsigned)p.N : 8u) * (unsigned)p.ldb * 2u;
 
   // ---- fragment read offsets (bytes inside a unit) -------------------------------------------------
   unsigned aoff0, aoff1, boff0, boff1;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     const unsigned k = (unsigned)(over ? kk - nk : kk) * 128u;
     unsigned base;
     if (IS_A) base = (unsigned)(over ? nxt_m0 : cur_m0) * (unsigned)p.lda * 2u + (HALF ? aStepMh : 0u) + k;
-    else base = (unsigned)(over ? nxt_n0 : cur_n0) * (unsigned)p.ldb * 2u + (HALF ? bStepNh : 0u) + k;
+    else base = ((unsigned)(over ? nxt_n0 : cur_n0) >> (kPair ? 1 : 0)) * (unsigned)p.ldb * 2u + (HALF ? bStepNh : 0u) + k;
     if (over && !have_nxt) base = kOob;
     const unsigned ldsu = copy * kCopy + ((IS_A ? 0 : 2) + HALF) * kUnit;
     const unsigned v0 = base + (IS_A ? voffA0 : voffB0);
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(p.aux_out, 0, (int)p.aux_bytes, 0x00020000);
-  constexpr int kStores = (EPI == kEpiGelu) ? 32 : 16;   // epilogue stores per wave and tile
+  // epilogue stores per wave and tile
+  constexpr int kStores = (EPI == kEpiGelu || EPI == kEpiDswiglu) ? 32 : (EPI == kEpiSwiglu ? 24 : 16);
 
   // ---- prologue: both K-tile copies of the first tile (the order of the stream) ----------------------
   issue(TA{}, H0{}, 0, 0);
@@ -435,7 +440,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 
     // ---- epilogue (no barriers, no LDS-DMA: only stores, counted in the next tile's first waits) ----
     {
-      const int colq = cur_n0 + 64 * wc + 16 * q;          // first of this lane's 16 columns
+      // first of this lane's 16 columns (paired tiles: of its 8 output columns)
+      const int colq = kPair ? (cur_n0 >> 1) + 32 * wc + 8 * q : cur_n0 + 64 * wc + 16 * q;
       const bool col_ok = colq < p.N;
       float bv[16];
       if (BIAS) {
@@ -468,6 +474,56 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
                 v[2 * j] += a0; v[2 * j + 1] += a1; v[8 + 2 * j] += a2; v[8 + 2 * j + 1] += a3;
               }
             }
+          }
+          if (EPI == kEpiSwiglu) {
+            // v[0..7] = gate, v[8..15] = up of output columns colq .. colq + 7
+            u32x4 o, hg, hu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float a2[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const float g = v[2 * j + e];
+                a2[e] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g)) * v[8 + 2 * j + e];
+              }
+              o[j] = pack_bf16x2(a2[0], a2[1]);
+              hg[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+              hu[j] = pack_bf16x2(v[8 + 2 * j], v[8 + 2 * j + 1]);
+            }
+            const unsigned oc = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)colq) * 2u : 0x80000000u;
+            const unsigned og = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsC, oc, 0, kStoreAux);
+            __builtin_amdgcn_raw_buffer_store_b128(hg, rsG, og, 0, kStoreAux);
+            __builtin_amdgcn_raw_buffer_store_b128(hu, rsG, ok ? og + (unsigned)p.N * 2u : 0x80000000u, 0, kStoreAux);
+            continue;
+          }
+          if (EPI == kEpiDswiglu) {
+            // v = d(loss)/d(act) for columns colq .. colq + 15; [gate | up] from aux_in, [dgate | dup] to c
+            const unsigned xoff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0u;
+            const u32x4* gp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux_in) + xoff);
+            const u32x4* up = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux_in) + xoff + (ok ? (unsigned)p.N * 2u : 0u));
+            const u32x4 g0 = gp[0], g1 = gp[1], u0 = up[0], u1 = up[1];
+            u32x4 dg0, dg1, du0, du1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float dgv[4], duv[4];
+              const float gs[4] = {lo_bf16(g0[j]), hi_bf16(g0[j]), lo_bf16(g1[j]), hi_bf16(g1[j])};
+              const float us[4] = {lo_bf16(u0[j]), hi_bf16(u0[j]), lo_bf16(u1[j]), hi_bf16(u1[j])};
+              const float ds[4] = {v[2 * j], v[2 * j + 1], v[8 + 2 * j], v[8 + 2 * j + 1]};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gs[e]));
+                duv[e] = ds[e] * gs[e] * sg;
+                dgv[e] = ds[e] * us[e] * sg * (1.0f + gs[e] * (1.0f - sg));
+              }
+              dg0[j] = pack_bf16x2(dgv[0], dgv[1]);
+              dg1[j] = pack_bf16x2(dgv[2], dgv[3]);
+              du0[j] = pack_bf16x2(duv[0], duv[1]);
+              du1[j] = pack_bf16x2(duv[2], duv[3]);
+            }
+            store_rows16(rsC, dg0, dg1, row0, colq, (unsigned)p.ldc, col_ok);
+            store_rows16(rsC, du0, du1, row0, colq + p.N, (unsigned)p.ldc, col_ok);
+            continue;
           }
           u32x4 o0, o1;
           if (EPI == kEpiGelu) {
@@ -546,24 +602,32 @@ bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long 
   return gemm_nt_shape_ok(M, N, K, lda, ldb, ldc, ld_aux, has_bias);
 }
 
+bool gemm_nt_pair_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ld_act,
+                     long long ld_pair) {
+  return gemm_nt_pair_shape_ok(M, N, K, lda, ldb, ld_act, ld_pair);
+}
+
 int g_gemm_nt_variant = 0;   // benchmark knob: bit 0 = one barrier per phase, bit 1 = drop the stores (timing only)
 void gemm_nt_set_variant(int v) { g_gemm_nt_variant = v; }
 
 void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   if (a.M == 0 || a.N == 0) return;
   a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 255) / 256;
+  const long long b_rows = epi == kEpiSwiglu ? 2ll * a.N : a.N;           // weight rows
+  const long long c_cols = epi == kEpiDswiglu ? 2ll * a.N : a.N;          // columns of c
+  const long long x_cols = (epi == kEpiSwiglu || epi == kEpiDswiglu) ? 2ll * a.N : a.N;   // columns of the auxiliary tensor
+  a.tiles_n = epi == kEpiSwiglu ? (a.N + 127) / 128 : (a.N + 255) / 256;
   a.a_bytes = (unsigned)(((long long)a.M - 1) * a.lda * 2 + (long long)a.K * 2);
-  a.b_bytes = (unsigned)(((long long)a.N - 1) * a.ldb * 2 + (long long)a.K * 2);
-  a.c_bytes = (unsigned)(((long long)a.M - 1) * a.ldc * 2 + (long long)a.N * 2);
-  a.aux_bytes = (unsigned)(((long long)a.M - 1) * a.ld_aux * 2 + (long long)a.N * 2);
+  a.b_bytes = (unsigned)((b_rows - 1) * a.ldb * 2 + (long long)a.K * 2);
+  a.c_bytes = (unsigned)(((long long)a.M - 1) * a.ldc * 2 + c_cols * 2);
+  a.aux_bytes = (unsigned)(((long long)a.M - 1) * a.ld_aux * 2 + x_cols * 2);
   if (g_gemm_nt_variant & 2) a.c_bytes = a.aux_bytes = 0;
   a.skew_ticks = (g_gemm_nt_variant >> 8);
   const int grid = gemm_nt_grid(a.tiles_m, a.tiles_n, num_cus);
   static bool attr = false;
 #define DPA_GNT_ALL(F)                                                                  \
   F(kEpiNone, false) F(kEpiNone, true) F(kEpiGelu, false) F(kEpiGelu, true) F(kEpiMul, false) F(kEpiMul, true) \
-  F(kEpiAdd, false) F(kEpiAdd, true)
+  F(kEpiAdd, false) F(kEpiAdd, true) F(kEpiSwiglu, false) F(kEpiDswiglu, false)
   if (!attr) {
 #define DPA_GNT_ATTR(E, B)                                                                                        \
   (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, B, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); \

@@ -85,4 +85,16 @@ inline bool gemm_nt_shape_ok(long long M, long long N, long long K, long long ld
   return true;
 }
 
+// The SwiGLU forms of the NT GEMM (paired gate / up columns): N gate columns, an [M, N] tensor with row stride
+// ld_act and an [M, 2N] tensor with row stride ld_pair; the weight has 2N rows in the forward form and N in the
+// backward form (the larger is checked).
+inline bool gemm_nt_pair_shape_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ld_act,
+                                  long long ld_pair) {
+  const long long lim = 0x80000000ll;
+  if (N < 16 || N >= lim / 2 || N % 16 != 0) return false;
+  if (!gemm_nt_shape_ok(M, 2 * N, K, lda, ldb, ld_pair, ld_pair, false)) return false;
+  if (ld_act % 8 != 0 || ld_act < N || ld_act >= lim || M * ld_act * 2 >= lim) return false;
+  return true;
+}
+
 }  // namespace dpa

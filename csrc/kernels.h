@@ -113,9 +113,14 @@ void wgrad_finish_many(const float* ws, const long long* dst_ptrs, int count, lo
 //   kEpiGelu : c = GELU_erf(v), aux_out = GELU_erf'(v)      (aux_out [M, N], row stride ld_aux)
 //   kEpiMul  : c = v * aux_in                                (aux_in  [M, N], row stride ld_aux)
 //   kEpiAdd  : c = v + aux_in
+//   kEpiSwiglu  : b is [2N, K] (gate rows 0..N-1, up rows N..2N-1): c[M, N] = silu(a gate^T) * (a up^T), and
+//                 aux_out[M, 2N] (row stride ld_aux) receives the pre-activation [gate | up] for the backward
+//                 pass. An output tile pairs 128 gate with the 128 matching up columns inside each lane.
+//   kEpiDswiglu : c[M, 2N] (row stride ldc) = [v * up * silu'(gate) | v * silu(gate)] with [gate | up] =
+//                 aux_in[M, 2N] (row stride ld_aux): the input gradient of the SwiGLU from v = dy W_proj.
 // K % 64 == 0, K >= 128, N % 16 == 0, rows 16-byte aligned, every tensor below 4 GB - 16 MB,
 // bias only for N <= 8192 (gemm_nt_ok checks all of it).
-enum { kEpiNone = 0, kEpiGelu = 1, kEpiMul = 2, kEpiAdd = 3 };
+enum { kEpiNone = 0, kEpiGelu = 1, kEpiMul = 2, kEpiAdd = 3, kEpiSwiglu = 4, kEpiDswiglu = 5 };
 struct GemmNtArgs {
   const void *a, *b;
   void* c;
@@ -130,6 +135,10 @@ struct GemmNtArgs {
 };
 bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
                 bool has_bias);
+// the two SwiGLU forms: N = number of gate (= up) columns; ld_act the row stride of the [M, N] tensor, ld_pair that
+// of the [M, 2N] one
+bool gemm_nt_pair_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ld_act,
+                     long long ld_pair);
 void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st);
 void gemm_nt_set_variant(int v);   // benchmark knob, see csrc/gemm_nt.hip
 // out[C, R] = in[R, C]^T (bf16, R % 8 == 0 and C % 8 == 0, contiguous).

@@ -368,6 +368,9 @@ class MLP(nn.Module):
         if self.non_linearity == "gelu" and ops.mlp_gelu_supported(x, self.c_fc.weight, self.c_proj.weight):
             # both products on the own GEMM, GELU / GELU' in its epilogues
             return _drop(ops.mlp_gelu(x, self.c_fc.weight, self.c_proj.weight, sole_use=True), self.p_drop, self.training)
+        if self.non_linearity == "swiglu" and ops.mlp_swiglu_supported(x, self.c_fc.weight, self.c_proj.weight):
+            # gate and up columns paired inside the c_fc GEMM's tiles, SwiGLU and its gradient in the epilogues
+            return _drop(ops.mlp_swiglu(x, self.c_fc.weight, self.c_proj.weight, sole_use=True), self.p_drop, self.training)
         h = ops.linear(x, self.c_fc.weight, sole_use=True)
         h = ops.swiglu(h) if self.non_linearity == "swiglu" else self._act(h)
         return _drop(ops.linear(h, self.c_proj.weight, sole_use=True), self.p_drop, self.training)

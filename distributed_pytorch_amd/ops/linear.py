@@ -107,7 +107,7 @@ def _direct_bias_target(b_param):
 # Forward y = x W^T and input gradient dx = dy W both run on the same kernel (both operands
 # contraction-contiguous): the input gradient takes W^T, transposed once per weight version.
 GEMM_MIN_ROWS = int(os.environ.get("DPA_GEMM_MIN_ROWS", 512))   # below this the 256-row tiles are mostly padding
-_EPI_NONE, _EPI_GELU, _EPI_MUL, _EPI_ADD = 0, 1, 2, 3
+_EPI_NONE, _EPI_GELU, _EPI_MUL, _EPI_ADD, _EPI_SWIGLU, _EPI_DSWIGLU = 0, 1, 2, 3, 4, 5
 _WT_CACHE: dict = {}
 _WEIGHTS_EPOCH = 0
 
@@ -250,6 +250,57 @@ class _MlpGeluFn(torch.autograd.Function):
             dx = _input_grad(dh, w_fc).view(x.shape)
         dw_fc, _ = _param_grads(ctx.fc_param, None, dh, x2, ctx.needs_input_grad[1], False)
         return dx, dw_fc, dw_proj, None
+
+
+class _MlpSwigluFn(torch.autograd.Function):
+    """``c_proj(silu(gate) * up)`` with ``[gate | up] = c_fc(x)`` (reference: single-gpu/model.py:388-398,
+    SwiGLU branch) with the activation inside the GEMM epilogues: the c_fc product pairs every gate column
+    with its up column inside one output tile and writes the activation and the pre-activation; in backward
+    the input gradient of c_proj leaves its GEMM already turned into ``[dgate | dup]``."""
+
+    @staticmethod
+    def forward(ctx, x, w_fc, w_proj, sole_use):
+        x2 = x.reshape(-1, x.shape[-1])
+        act, h = ops().gemm_nt(x2, w_fc, None, _EPI_SWIGLU, None)
+        y = ops().gemm_nt(act, w_proj, None, _EPI_NONE, None)[0]
+        ctx.save_for_backward(x, w_fc, w_proj, act, h)
+        ctx.fc_param = w_fc if sole_use else None
+        ctx.proj_param = w_proj if sole_use else None
+        return torch.ops.aten._unsafe_view(y, (*x.shape[:-1], w_proj.shape[0]))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_fc, w_proj, act, h = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dh = ops().gemm_nt(dy2, transposed_weight(w_proj), None, _EPI_DSWIGLU, h)[0]   # [M, 2U] = [dgate | dup]
+        dw_proj, _ = _param_grads(ctx.proj_param, None, dy2, act, ctx.needs_input_grad[2], False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _input_grad(dh, w_fc).view(x.shape)
+        dw_fc, _ = _param_grads(ctx.fc_param, None, dh, x2, ctx.needs_input_grad[1], False)
+        return dx, dw_fc, dw_proj, None
+
+
+def mlp_swiglu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor) -> bool:
+    if not (use_hip(x, w_fc, w_proj) and x.dtype == torch.bfloat16 and w_fc.dtype == torch.bfloat16
+            and w_proj.dtype == torch.bfloat16 and hasattr(ops(), "gemm_nt_pair_supported")):
+        return False
+    if os.environ.get("DPA_LIBRARY_GEMM", "0") == "1":
+        return False
+    x2 = x.reshape(-1, x.shape[-1])
+    two_up, C = w_fc.shape
+    up = two_up // 2
+    if x2.shape[0] < GEMM_MIN_ROWS or two_up % 2 or tuple(w_proj.shape) != (C, up) or not w_proj.is_contiguous():
+        return False
+    if not (up % 64 == 0 and up >= 128 and C % 64 == 0 and C >= 128 and x2.shape[0] * max(two_up, C) * 2 < 2 ** 31):
+        return False
+    return bool(ops().gemm_nt_pair_supported(x2, w_fc, _EPI_SWIGLU, None))
+
+
+def mlp_swiglu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False) -> torch.Tensor:
+    """Fused SwiGLU feed-forward block; callers check ``mlp_swiglu_supported`` first."""
+    return _MlpSwigluFn.apply(x, w_fc, w_proj, sole_use)
 
 
 def mlp_gelu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor) -> bool:

@@ -139,6 +139,20 @@ static void test_gemm_shapes() {
   CHECK(!gemm_nt_shape_ok(64, 768, 768, 768, 768, 768, big - 7, false));
 }
 
+static void test_gemm_pair_shapes() {
+  using dpa::gemm_nt_pair_shape_ok;
+  // N gate columns; [M, N] activation with row stride ld_act, [M, 2N] pre-activation with row stride ld_pair
+  CHECK(gemm_nt_pair_shape_ok(65536, 3072, 768, 768, 768, 3072, 6144));
+  CHECK(gemm_nt_pair_shape_ok(2100, 1088, 128, 128, 128, 1088, 2176));
+  CHECK(!gemm_nt_pair_shape_ok(2100, 1080, 128, 128, 128, 1080, 2160));       // N not a multiple of 16
+  CHECK(!gemm_nt_pair_shape_ok(2100, 1088, 128, 128, 128, 1088, 2000));       // pair pitch shorter than 2N
+  CHECK(!gemm_nt_pair_shape_ok(2100, 1088, 128, 128, 128, 1000, 2176));       // activation pitch shorter than N
+  CHECK(!gemm_nt_pair_shape_ok(262144, 4096, 768, 768, 768, 4096, 8192));     // [M, 2N] passes 2 GiB
+  const long long big = 0x7fffffffffffffffll;
+  CHECK(!gemm_nt_pair_shape_ok(64, big - 15, 768, 768, 768, big - 15, big - 15));
+  CHECK(!gemm_nt_pair_shape_ok(64, (big / 2) & ~15ll, 768, 768, 768, 768, 768));
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::fprintf(stderr, "usage: host_checks <scratch dir>\n");
@@ -147,6 +161,7 @@ int main(int argc, char** argv) {
   test_token_stream(argv[1]);
   test_gemm_walk();
   test_gemm_shapes();
+  test_gemm_pair_shapes();
   if (g_failed) {
     std::fprintf(stderr, "%d check(s) failed\n", g_failed);
     return 1;

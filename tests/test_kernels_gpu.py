@@ -926,3 +926,55 @@ def test_rope_qkv_inplace_matches_eager_and_rotates_the_gradient_back():
     want_g = _rope_eager(g.float()[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, 5, True)
     assert torch.allclose(x.grad[..., : (nh + nkv) * hs].float().view(B, T, nh + nkv, hs), want_g, atol=2e-2, rtol=2e-2)
     assert torch.equal(x.grad[..., (nh + nkv) * hs:], g[..., (nh + nkv) * hs:])
+
+
+@pytest.mark.parametrize("M,U,K", [(1024, 256, 256), (2100, 1088, 128), (4096, 3072, 768)])
+def test_gemm_nt_swiglu_epilogues_match_fp32(M, U, K):
+    """Forward: act = silu(x Wg^T) * (x Wu^T) with [gate | up] also returned; backward: [dgate | dup] from
+    d(act) = dy Wp. Both against fp32 PyTorch on the bf16 operands (ragged rows and a ragged last tile)."""
+    o = torch.ops.dpa
+    torch.manual_seed(M + U)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(2 * U, K, device="cuda") / K ** 0.5).bfloat16()
+    assert o.gemm_nt_pair_supported(x, w, 4, None)
+    act, h = o.gemm_nt(x, w, None, 4, None)
+    hf = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(hf[:, :U]) * hf[:, U:]
+    assert act.shape == (M, U) and h.shape == (M, 2 * U)
+    assert (h.float() - hf).abs().max() <= 2e-2 * hf.abs().max()
+    assert (act.float() - want).abs().max() <= 2e-2 * want.abs().max() + 1e-3
+    # backward form: v = dy @ wp^T (NT on the transposed projection weight), h from the forward
+    C = 256
+    dy = torch.randn(M, C, device="cuda").bfloat16()
+    wpt = (torch.randn(U, C, device="cuda") / C ** 0.5).bfloat16()      # W_proj^T: [U, C]
+    assert o.gemm_nt_pair_supported(dy, wpt, 5, h)
+    dh = o.gemm_nt(dy, wpt, None, 5, h)[0]
+    assert dh.shape == (M, 2 * U)
+    v = dy.float() @ wpt.float().t()
+    g, u = h.float()[:, :U], h.float()[:, U:]
+    s = torch.sigmoid(g)
+    want_dg = v * u * s * (1 + g * (1 - s))
+    want_du = v * g * s
+    assert (dh[:, :U].float() - want_dg).abs().max() <= 2e-2 * want_dg.abs().max() + 1e-3
+    assert (dh[:, U:].float() - want_du).abs().max() <= 2e-2 * want_du.abs().max() + 1e-3
+
+
+def test_mlp_swiglu_fused_matches_unfused():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(3)
+    M, C, U = 2048, 256, 512
+    x = torch.randn(4, M // 4, C, device="cuda").bfloat16().requires_grad_()
+    w_fc = (torch.randn(2 * U, C, device="cuda") / C ** 0.5).bfloat16().requires_grad_()
+    w_pr = (torch.randn(C, U, device="cuda") / U ** 0.5).bfloat16().requires_grad_()
+    assert ops.mlp_swiglu_supported(x, w_fc, w_pr)
+    y = ops.mlp_swiglu(x, w_fc, w_pr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = [y.detach().float(), x.grad.float(), w_fc.grad.float(), w_pr.grad.float()]
+    xr, fr, pr = (t.detach().float().requires_grad_() for t in (x, w_fc, w_pr))
+    hr = xr @ fr.t()
+    yr = (torch.nn.functional.silu(hr[..., :U]) * hr[..., U:]) @ pr.t()
+    yr.backward(gy.float())
+    for a, b, name in zip(got, [yr.detach(), xr.grad, fr.grad, pr.grad], ["y", "dx", "dw_fc", "dw_proj"]):
+        err = ((a - b).norm() / b.norm()).item()
+        assert err < 2e-2, f"{name}: relative error {err:.4f}"
