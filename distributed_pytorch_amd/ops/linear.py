@@ -286,7 +286,7 @@ def mlp_swiglu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tens
     if not (use_hip(x, w_fc, w_proj) and x.dtype == torch.bfloat16 and w_fc.dtype == torch.bfloat16
             and w_proj.dtype == torch.bfloat16 and hasattr(ops(), "gemm_nt_pair_supported")):
         return False
-    if os.environ.get("DPA_LIBRARY_GEMM", "0") == "1":
+    if os.environ.get("DPA_LIBRARY_GEMM", "0") == "1" or os.environ.get("DPA_FUSED_SWIGLU", "1") == "0":
         return False
     x2 = x.reshape(-1, x.shape[-1])
     two_up, C = w_fc.shape
