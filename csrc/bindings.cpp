@@ -698,23 +698,26 @@ std::tuple<Tensor, Tensor> moe_topk_gate(const Tensor& logits, const std::option
   return {idx, gates};
 }
 
-// (row_of_pair [npairs] int64, block_group [rows / 128] int32, seg_start, seg_rows, counts [E] int64)
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> moe_plan(const Tensor& idx, int64_t n_experts, int64_t rows) {
+// (row_of_pair [npairs] int64, block_group [rows / block] int32, seg_start, seg_rows, counts [E] int64);
+// block = rows per GEMM row block of the padded layout (128 or 256), 0 = dense (unpadded) layout
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> moe_plan(const Tensor& idx, int64_t n_experts, int64_t rows,
+                                                            int64_t block) {
   TORCH_CHECK(idx.is_cuda() && idx.scalar_type() == at::kLong && idx.is_contiguous(), "moe_plan: int64 expert ids");
   const int64_t npairs = idx.numel();
-  const bool dense = rows == npairs;     // unpadded layout (expert-sorted send order)
+  const bool dense = block == 0;     // unpadded layout (expert-sorted send order)
   TORCH_CHECK(n_experts >= 1 && n_experts <= 64, "moe_plan: E <= 64");
-  TORCH_CHECK(dense || (rows % 128 == 0 && rows >= npairs + n_experts * 127),
-              "moe_plan: rows is either the pair count (dense) or a multiple of 128 >= pairs + 127 * E");
+  TORCH_CHECK(dense ? rows == npairs
+                    : ((block == 128 || block == 256) && rows % block == 0 && rows >= npairs + n_experts * (block - 1)),
+              "moe_plan: rows is the pair count (block 0) or a multiple of block (128 | 256) >= pairs + (block - 1) * E");
   auto opt = idx.options();
   Tensor row_of_pair = at::empty({npairs}, opt);
-  Tensor block_group = at::empty({dense ? 0 : rows / 128}, opt.dtype(at::kInt));
+  Tensor block_group = at::empty({dense ? 0 : rows / block}, opt.dtype(at::kInt));
   Tensor seg_start = at::empty({n_experts}, opt), seg_rows = at::empty({n_experts}, opt);
   Tensor counts = at::empty({n_experts}, opt);
   const int nb = dpa::moe_plan_blocks(npairs);
   Tensor hist = at::empty({std::max<int64_t>(nb, 1) * n_experts}, opt.dtype(at::kInt));
-  dpa::moe_plan((const long long*)idx.data_ptr<int64_t>(), npairs, (int)n_experts, dense ? 0 : (int)(rows / 128),
-                dense ? 1 : 128, hist.data_ptr<int>(), (long long*)row_of_pair.data_ptr<int64_t>(),
+  dpa::moe_plan((const long long*)idx.data_ptr<int64_t>(), npairs, (int)n_experts, dense ? 0 : (int)(rows / block),
+                dense ? 1 : (int)block, hist.data_ptr<int>(), (long long*)row_of_pair.data_ptr<int64_t>(),
                 dense ? nullptr : block_group.data_ptr<int>(), (long long*)seg_start.data_ptr<int64_t>(),
                 (long long*)seg_rows.data_ptr<int64_t>(), (long long*)counts.data_ptr<int64_t>(), cur_stream());
   return {row_of_pair, block_group, seg_start, seg_rows, counts};
@@ -889,6 +892,55 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt(const Tensor& a, const Tensor&
   return {c, aux_out};
 }
 
+// Grouped form of the NT GEMM (csrc/gemm_nt.hip): c[rows, N] = epi(a[rows, K] * W_g^T) with W_g = the [N, K] matrix
+// at address w_ptrs[block_group[row / 256]]. epi: 0 none, 1 GELU (also returns GELU'), 2 multiply by aux [rows, N].
+std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const Tensor& w_ptrs, int64_t N, int64_t ldw,
+                                                         int64_t epi, const std::optional<Tensor>& aux,
+                                                         const Tensor& block_group) {
+  check_rows2d(a, "a");
+  const int64_t rows = a.size(0), K = a.size(1);
+  TORCH_CHECK(epi == dpa::kEpiNone || epi == dpa::kEpiGelu || epi == dpa::kEpiMul, "gemm_nt_grouped: epilogue 0, 1 or 2");
+  TORCH_CHECK((epi == dpa::kEpiMul) == aux.has_value(), "gemm_nt_grouped: the multiply epilogue (and only it) takes aux");
+  TORCH_CHECK(rows % 256 == 0 && rows > 0, "gemm_nt_grouped: rows must be padded to a multiple of 256");
+  TORCH_CHECK(w_ptrs.is_cuda() && w_ptrs.scalar_type() == at::kLong && w_ptrs.is_contiguous() && w_ptrs.numel() >= 1,
+              "w_ptrs: int64 cuda");
+  TORCH_CHECK(block_group.is_cuda() && block_group.scalar_type() == at::kInt && block_group.is_contiguous() &&
+                  block_group.numel() == rows / 256,
+              "block_group: int32 [rows / 256]");
+  int64_t ld_aux = N;
+  if (aux.has_value()) {
+    check_rows2d(*aux, "aux");
+    TORCH_CHECK(aux->size(0) == rows && aux->size(1) == N, "gemm_nt_grouped: aux is [rows, N]");
+    ld_aux = aux->stride(0);
+  }
+  TORCH_CHECK(dpa::gemm_nt_ok(rows, N, K, a.stride(0), ldw, N, ld_aux, false), "gemm_nt_grouped: unsupported shape ", rows,
+              "x", N, "x", K);
+  Tensor c = at::empty({rows, N}, a.options());
+  std::optional<Tensor> aux_out;
+  dpa::GemmNtArgs g{};
+  g.a = a.data_ptr();
+  g.b = nullptr;
+  g.c = c.data_ptr();
+  g.M = (int)rows;
+  g.N = (int)N;
+  g.K = (int)K;
+  g.lda = a.stride(0);
+  g.ldb = ldw;
+  g.ldc = N;
+  g.ld_aux = ld_aux;
+  if (epi == dpa::kEpiGelu) {
+    aux_out = at::empty({rows, N}, a.options());
+    g.aux_out = aux_out->data_ptr();
+  } else if (aux.has_value()) {
+    g.aux_in = aux->data_ptr();
+  }
+  g.w_ptrs = (const long long*)w_ptrs.data_ptr<int64_t>();
+  g.block_group = block_group.data_ptr<int>();
+  g.ngroups = (int)w_ptrs.numel();
+  dpa::gemm_nt(g, (int)epi, gemm_cus(), cur_stream());
+  return {c, aux_out};
+}
+
 Tensor transpose_bf16(const Tensor& x) {
   TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == at::kBFloat16 && x.is_contiguous() &&
                   x.size(0) % 8 == 0 && x.size(1) % 8 == 0 && reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
@@ -901,6 +953,7 @@ Tensor transpose_bf16(const Tensor& x) {
 TORCH_LIBRARY(dpa, m) {
   m.def("gemm_nt(Tensor a, Tensor b, Tensor? bias, int epi, Tensor? aux) -> (Tensor, Tensor?)");
   m.def("gemm_nt_supported(Tensor a, Tensor b, Tensor? bias, Tensor? aux) -> bool");
+  m.def("gemm_nt_grouped(Tensor a, Tensor w_ptrs, int n, int ldw, int epi, Tensor? aux, Tensor block_group) -> (Tensor, Tensor?)");
   m.def("gemm_nt_pair_supported(Tensor a, Tensor b, int epi, Tensor? aux) -> bool");
   m.def("gemm_nt_set_variant(int v) -> ()");
   m.def("transpose_bf16(Tensor x) -> Tensor");
@@ -908,7 +961,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
   m.def("wgrad2_direct(Tensor dy, Tensor x, Tensor(a!) dw_acc, Tensor(b!)? db_acc) -> ()");
   m.def("moe_topk_gate(Tensor logits, Tensor? bias, int k) -> (Tensor, Tensor)");
-  m.def("moe_plan(Tensor idx, int n_experts, int rows) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("moe_plan(Tensor idx, int n_experts, int rows, int block) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("grouped_gemm(Tensor a, Tensor w_ptrs, int w_rows, int w_cols, bool w_is_kn, Tensor block_group) -> Tensor");
   m.def("grouped_wgrad(Tensor dy, Tensor x, Tensor seg_start, Tensor seg_rows) -> Tensor");
   m.def("moe_scatter_rows(Tensor src, Tensor row_of_pair, int k, int rows_out) -> Tensor");
@@ -962,6 +1015,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("ws_to_many", ws_to_many);
   m.impl("gemm_nt", gemm_nt);
+  m.impl("gemm_nt_grouped", gemm_nt_grouped);
   m.impl("transpose_bf16", transpose_bf16);
   m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);
   m.impl("wgrad2_direct", wgrad2_direct);

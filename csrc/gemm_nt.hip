@@ -119,7 +119,7 @@ struct KtCfg {
 
 // ABL (timing-only ablations, results wrong): 1 = no LDS-DMA in the K-loop, 2 = no fragment reads, 4 = no
 // barriers, 8 = no MFMAs.
-template <int EPI, bool BIAS, int SYNC, int ABL = 0>
+template <int EPI, bool BIAS, int SYNC, int ABL = 0, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   constexpr bool kPair = EPI == kEpiSwiglu;   // output tile = 128 gate columns paired with their 128 up columns
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,6 +208,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     nxt_m0 = t1.m0;
     nxt_n0 = t1.n0;
   }
+  // Grouped mode: the weight matrix of a tile is the one of its 256-row block's group; a block without a
+  // group (padding past the last segment) gets an empty buffer range, i.e. multiplies by zeros. The
+  // descriptor of the tile after next is formed a whole tile ahead of its first use.
+  auto group_rsrc = [&](int m0) -> rsrc_t {
+    const int g = p.block_group[m0 >> 8];
+    const bool live = g >= 0 && g < p.ngroups;
+    return make_rsrc(reinterpret_cast<const void*>(p.w_ptrs[live ? g : 0]), live ? p.b_bytes : 0u);
+  };
+  rsrc_t rsB_cur = rsB, rsB_nxt = rsB;
+  if (GROUPED) {
+    rsB_cur = group_rsrc(cur_m0);
+    rsB_nxt = have_nxt ? group_rsrc(nxt_m0) : rsB_cur;
+  }
   // a dead refill (past the last tile) is aimed at offsets >= 2 GiB, beyond every buffer: it reads zeros
   const unsigned kOob = 0x80000000u;
 
@@ -229,8 +242,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       asm volatile("" ::"v"(v0), "v"(v1), "s"(ldsu));
       return;
     }
-    dma16(pieceLds0 + ldsu, v0, IS_A ? rsA : rsB);
-    dma16(pieceLds1 + ldsu, v1, IS_A ? rsA : rsB);
+    const rsrc_t rs = IS_A ? rsA : (GROUPED ? (over ? rsB_nxt : rsB_cur) : rsB);
+    dma16(pieceLds0 + ldsu, v0, rs);
+    dma16(pieceLds1 + ldsu, v1, rs);
   };
   using TA = std::true_type;
   using TB = std::false_type;
@@ -557,6 +571,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       nxt_m0 = t2.m0;
       nxt_n0 = t2.n0;
     }
+    if (GROUPED) {
+      rsB_cur = rsB_nxt;
+      if (have_nxt) rsB_nxt = group_rsrc(nxt_m0);
+    }
   }
   if (SYNC == 0 && wr == 0) barrier();   // pairs with the extra barrier the second wave group started with
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (zero-fill) LDS-DMA before the LDS is released
@@ -650,6 +668,22 @@ void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
 #undef DPA_GNT_ABL
   }
 #endif
+  if (a.w_ptrs != nullptr) {   // grouped mode: bias-free, epilogues none / GELU / multiply
+#define DPA_GNT_GROUPED(E)                                                                                          \
+  if (epi == E) {                                                                                                   \
+    static bool once = false;                                                                                       \
+    if (!once) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, false, 0, 0, true>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                                  \
+      once = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL((gemm_nt_kernel<E, false, 0, 0, true>), dim3(grid), dim3(512), kLds, st, a);                 \
+    return;                                                                                                         \
+  }
+    DPA_GNT_GROUPED(kEpiNone) DPA_GNT_GROUPED(kEpiGelu) DPA_GNT_GROUPED(kEpiMul)
+#undef DPA_GNT_GROUPED
+    return;
+  }
   const bool bias = a.bias != nullptr;
 #define DPA_GNT_LAUNCH(E, B)                                                                              \
   if (epi == E && bias == B) {                                                                            \

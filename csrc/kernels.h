@@ -132,6 +132,12 @@ struct GemmNtArgs {
   unsigned a_bytes, b_bytes, c_bytes, aux_bytes;   // filled by gemm_nt()
   int tiles_m, tiles_n;                            // filled by gemm_nt()
   int skew_ticks;                                  // filled by gemm_nt() (benchmark knob)
+  // Grouped mode (MoE experts): b is ignored; every 256-row block of a uses the weight matrix
+  // w_ptrs[block_group[row / 256]] ([N, K], row stride ldb, all of one shape); a block whose group is outside
+  // [0, ngroups) multiplies by zeros. M must be a multiple of 256. Epilogues none / GELU / multiply only.
+  const long long* w_ptrs;
+  const int* block_group;
+  int ngroups;
 };
 bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
                 bool has_bias);

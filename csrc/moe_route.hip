@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void moe_plan_scan_kernel(int* __restrict__ his
       run += v;
     }
   }
-  const int padded = lane < E ? (run + pad - 1) / pad * pad : 0;   // pad = 128 (GEMM blocks) or 1 (dense)
+  const int padded = lane < E ? (run + pad - 1) / pad * pad : 0;   // pad = 128 / 256 (GEMM row blocks) or 1 (dense)
   int incl = padded;                          // inclusive scan over the experts (lanes)
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -124,16 +124,16 @@ __global__ __launch_bounds__(64) void moe_plan_scan_kernel(int* __restrict__ his
     seg_rows[lane] = padded;
     counts[lane] = run;
     for (int b = 0; b < nblocks; ++b) tab[b * E + lane] += start;   // absolute row base
-    if (pad == 128)
-      for (int rb = start / 128; rb < (start + padded) / 128; ++rb) block_group[rb] = lane;
+    if (pad > 1)
+      for (int rb = start / pad; rb < (start + padded) / pad; ++rb) block_group[rb] = lane;
   }
   if (in_lds) {
     __syncthreads();
     for (int i = lane; i < total_cells; i += 64) hist[i] = sh[i];
   }
   const int total = __shfl(incl, 63, 64);
-  if (pad == 128)
-    for (int rb = total / 128 + lane; rb < nrb; rb += 64) block_group[rb] = E;   // blocks past the last segment
+  if (pad > 1)
+    for (int rb = total / pad + lane; rb < nrb; rb += 64) block_group[rb] = E;   // blocks past the last segment
 }
 
 __global__ __launch_bounds__(64) void moe_plan_place_kernel(const long long* __restrict__ idx, long long npairs, int E,

@@ -418,7 +418,8 @@ class MoE(nn.Module):
         topk_indices, topk_gates = ops.topk_gate(router_logits, self.expert_bias if cfg.aux_free else None, k)
         self._layout = None
         if self.dispatcher is None and x_flat.is_cuda:
-            self._layout = (topk_indices, ops.moe_plan(topk_indices, E))   # reused by routed_experts_local
+            # reused by routed_experts_local; the row-block size is the one of the kernels that will run there
+            self._layout = (topk_indices, ops.moe_plan(topk_indices, E, self._layout_block(x_flat)))
         with torch.no_grad():
             counts = self._layout[1][5] if self._layout is not None else ops.expert_counts(topk_indices, E)
             fi = counts.float() / n_tokens
@@ -427,6 +428,12 @@ class MoE(nn.Module):
         pi = F.softmax(router_logits, dim=1).mean(dim=0)
         aux_loss = (cfg.alpha if cfg.aux_free else cfg.coeff) * E * torch.sum(pi * fi)
         return topk_indices, topk_gates.to(x_flat.dtype), aux_loss
+
+    def _layout_block(self, x_flat) -> int:
+        routed = self.experts[self.n_shared:]
+        fcs = [e.expert.c_fc.weight for e in routed]
+        projs = [e.expert.c_proj.weight for e in routed]
+        return ops.grouped_layout_block(x_flat, fcs, projs, routed[0].expert.non_linearity, self.n_act_routed)
 
     def routed_experts_local(self, x_flat, topk_indices, topk_gates):
         """Routed experts on this rank. GPU path: grouped expert GEMMs over the padded expert-sorted

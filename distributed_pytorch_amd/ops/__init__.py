@@ -9,7 +9,8 @@ from .linear import (bump_weights_epoch, linear, mlp_gelu, mlp_gelu_supported, m
                      wgrad_supported)
 from .loss import (IGNORE_INDEX, cross_entropy, linear_cross_entropy, vocab_parallel_cross_entropy,
                    vocab_parallel_linear_cross_entropy)
-from .moe import (expert_counts, gather_combine, grouped_experts, grouped_experts_eager, grouped_supported,
+from .moe import (expert_counts, gather_combine, grouped_experts, grouped_experts_eager, grouped_layout_block,
+                  grouped_supported,
                   plan_dense, scatter_rows, topk_gate)
 from .moe import plan as moe_plan
 from .norm import add_layer_norm, layer_norm

@@ -25,9 +25,9 @@ from .._ext import ops, use_hip
 BLOCK = 128
 
 
-def padded_rows(npairs: int, n_experts: int) -> int:
-    """Static row count of the padded expert-sorted buffer."""
-    return (npairs + n_experts * (BLOCK - 1) + BLOCK - 1) // BLOCK * BLOCK
+def padded_rows(npairs: int, n_experts: int, block: int = BLOCK) -> int:
+    """Static row count of the padded expert-sorted buffer (expert segments padded to ``block`` rows)."""
+    return (npairs + n_experts * (block - 1) + block - 1) // block * block
 
 
 def expert_counts(topk_indices: torch.Tensor, n_experts: int) -> torch.Tensor:
@@ -38,32 +38,33 @@ def expert_counts(topk_indices: torch.Tensor, n_experts: int) -> torch.Tensor:
         0, flat, torch.ones_like(flat))
 
 
-def plan(topk_indices: torch.Tensor, n_experts: int):
-    """Device-side layout of the pairs (no host sync).
+def plan(topk_indices: torch.Tensor, n_experts: int, block: int = BLOCK):
+    """Device-side layout of the pairs (no host sync). ``block`` = rows of a GEMM row block: 128 for the
+    grouped kernels of ``csrc/gemm_grouped.hip``, 256 for the grouped mode of the NT GEMM.
 
     -> row_of_pair [N*k] int64 (row of pair ``t*k + s`` in the padded buffer),
-       block_group [rows/128] int32 (expert of each block, ``n_experts`` past the end),
+       block_group [rows/block] int32 (expert of each block, ``n_experts`` past the end),
        seg_start, seg_rows [E] int64 (padded segment of each expert), rows (python int),
        counts [E] int64.
     On the GPU this is the histogram / scan / placement kernel trio of ``csrc/moe_route.hip``; the
     PyTorch statement below (one stable sort) defines the same layout."""
     flat_e = topk_indices.reshape(-1)
     npairs = flat_e.numel()
-    rows = padded_rows(npairs, n_experts)
+    rows = padded_rows(npairs, n_experts, block)
     if use_hip(flat_e) and n_experts <= 64 and flat_e.dtype == torch.int64:
-        row_of_pair, block_group, seg_start, seg_rows, counts = ops().moe_plan(flat_e.contiguous(), n_experts, rows)
+        row_of_pair, block_group, seg_start, seg_rows, counts = ops().moe_plan(flat_e.contiguous(), n_experts, rows, block)
         return row_of_pair, block_group, seg_start, seg_rows, rows, counts
     order = torch.argsort(flat_e, stable=True)
     counts = expert_counts(flat_e, n_experts)
     cstart = torch.cumsum(counts, 0) - counts
-    seg_rows = (counts + (BLOCK - 1)) // BLOCK * BLOCK
+    seg_rows = (counts + (block - 1)) // block * block
     seg_end = torch.cumsum(seg_rows, 0)
     seg_start = seg_end - seg_rows
     e_sorted = flat_e[order]
     dest = seg_start[e_sorted] + (torch.arange(npairs, device=flat_e.device) - cstart[e_sorted])
     row_of_pair = torch.empty_like(order)
     row_of_pair[order] = dest
-    block_first = torch.arange(rows // BLOCK, device=flat_e.device) * BLOCK
+    block_first = torch.arange(rows // block, device=flat_e.device) * block
     block_group = torch.searchsorted(seg_end, block_first, right=True).to(torch.int32)
     return row_of_pair, block_group, seg_start.contiguous(), seg_rows.contiguous(), rows, counts
 
@@ -76,7 +77,7 @@ def plan_dense(topk_indices: torch.Tensor, n_experts: int):
     flat_e = topk_indices.reshape(-1)
     npairs = flat_e.numel()
     if use_hip(flat_e) and n_experts <= 64 and flat_e.dtype == torch.int64 and npairs > 0:
-        row_of_pair, _, _, _, counts = ops().moe_plan(flat_e.contiguous(), n_experts, npairs)
+        row_of_pair, _, _, _, counts = ops().moe_plan(flat_e.contiguous(), n_experts, npairs, 0)
         return row_of_pair, counts
     order = torch.argsort(flat_e, stable=True)
     row_of_pair = torch.empty_like(order)
@@ -271,6 +272,78 @@ class _GroupedExpertsFn(torch.autograd.Function):
         return (dx, dg, None, None, None, *g_fc, *g_proj)
 
 
+NT_BLOCK = 256   # row-block size of the grouped mode of the NT GEMM (its output tile has 256 rows)
+
+
+def _nt_grouped_ok(x_flat, fc, proj, act: str, k: int = 8) -> bool:
+    """GELU experts on the grouped mode of the dense NT GEMM (csrc/gemm_nt.hip): same persistent 256 x 256
+    kernel as the dense layers, the weight matrix chosen per 256-row block, GELU / GELU' and the dGELU
+    multiply in its epilogues. Needs the 256-row layout."""
+    if act != "gelu" or os.environ.get("DPA_MOE_NT", "1") == "0":
+        return False
+    if not (use_hip(x_flat) and x_flat.dtype == torch.bfloat16 and hasattr(ops(), "gemm_nt_grouped")):
+        return False
+    U, C = fc[0].shape
+    rows_bound = x_flat.shape[0] * k + len(fc) * NT_BLOCK      # every byte offset of the kernel stays below 2 GiB
+    return (C % 64 == 0 and C >= 128 and U % 64 == 0 and U >= 128 and tuple(proj[0].shape) == (C, U)
+            and rows_bound * max(U, C) * 2 < 2 ** 31)
+
+
+class _GroupedExpertsNtFn(torch.autograd.Function):
+    """The routed experts of a layer as four grouped NT GEMMs and two grouped weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x_flat, gates, topk_indices, layout, *weights):
+        E = len(weights) // 2
+        fc, proj = weights[:E], weights[E:]
+        k = topk_indices.shape[1]
+        row_of_pair, block_group, seg_start, seg_rows, rows = (layout or plan(topk_indices, E, NT_BLOCK))[:5]
+        assert block_group.numel() * NT_BLOCK == rows, "the grouped NT GEMM needs the 256-row layout"
+        xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows)
+        U, C = fc[0].shape
+        a, dact = ops().gemm_nt_grouped(xs, _ptr_table(fc), U, C, 1, None, block_group)
+        y = ops().gemm_nt_grouped(a, _ptr_table(proj), C, U, 0, None, block_group)[0]
+        gates_c = gates.contiguous()
+        out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
+        ctx.save_for_backward(xs, a, dact, y, gates_c, row_of_pair, block_group, seg_start, seg_rows)
+        ctx.params = weights
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .linear import transposed_weight
+        xs, a, dact, y, gates, row_of_pair, block_group, seg_start, seg_rows = ctx.saved_tensors
+        weights = ctx.params
+        E = len(weights) // 2
+        fc, proj = weights[:E], weights[E:]
+        U, C = fc[0].shape
+        needs = ctx.needs_input_grad[4:]
+        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        g_proj = [None] * E
+        if any(needs[E:]):
+            g_proj = _emit_wgrads(ops().grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
+        # dh = (dy W_proj) * gelu'(h): NT on the per-step cached transposes, the multiply in the epilogue
+        proj_t = [transposed_weight(w) for w in proj]          # [U, C] each
+        dh = ops().gemm_nt_grouped(dy, _ptr_table(proj_t), U, C, 2, dact, block_group)[0]
+        g_fc = [None] * E
+        if any(needs[:E]):
+            g_fc = _emit_wgrads(ops().grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            fc_t = [transposed_weight(w) for w in fc]          # [C, U] each
+            dxs = ops().gemm_nt_grouped(dh, _ptr_table(fc_t), C, U, 0, None, block_group)[0]
+            dx = ops().moe_gather_combine(dxs, row_of_pair, None, ctx.k)
+        dg = dgate.to(gates.dtype) if ctx.needs_input_grad[1] else None
+        return (dx, dg, None, None, *g_fc, *g_proj)
+
+
+def grouped_layout_block(x_flat, fc_weights, proj_weights, act: str, k: int = 8) -> int:
+    """Row-block size of the padded layout that ``grouped_experts`` will want for these operands (``k`` =
+    experts per token)."""
+    return NT_BLOCK if _nt_grouped_ok(x_flat, fc_weights, proj_weights, act, k) else BLOCK
+
+
 def grouped_supported(x_flat, fc_weights, proj_weights, act: str) -> bool:
     if act not in ("gelu", "swiglu") or not use_hip(x_flat) or x_flat.dtype != torch.bfloat16:
         return False
@@ -291,6 +364,11 @@ def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, 
     (``act`` = "gelu" or "swiglu") on the grouped HIP kernels. ``layout`` = a ``plan()`` result for
     ``topk_indices`` if the caller already has one."""
     assert len(fc_weights) == len(proj_weights)
+    if _nt_grouped_ok(x_flat, fc_weights, proj_weights, act, topk_indices.shape[1]) and \
+            (layout is None or layout[1].numel() * NT_BLOCK == layout[4]):
+        return _GroupedExpertsNtFn.apply(x_flat, topk_gates, topk_indices, layout, *fc_weights, *proj_weights)
+    if layout is not None and layout[1].numel() * BLOCK != layout[4]:
+        layout = None      # made for the other kernels' block size
     return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, layout, *fc_weights, *proj_weights)
 
 

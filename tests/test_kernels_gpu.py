@@ -398,9 +398,12 @@ def test_grouped_wgrad_segments():
             assert rel_err(out[g], ref) < 1e-5
 
 
+@pytest.mark.parametrize("nt", ["1", "0"])
 @pytest.mark.parametrize("act,E,k,Ntok,C,U", [("gelu", 8, 2, 4096, 768, 3072), ("swiglu", 3, 2, 1000, 256, 384),
                                               ("gelu", 4, 1, 77, 128, 128)])
-def test_grouped_experts_fwd_bwd(act, E, k, Ntok, C, U):
+def test_grouped_experts_fwd_bwd(act, E, k, Ntok, C, U, nt, monkeypatch):
+    # nt = "1": GELU experts on the grouped mode of the NT GEMM (256-row blocks); "0": the 128-row grouped kernels
+    monkeypatch.setenv("DPA_MOE_NT", nt)
     """The padded grouped path equals the dense-over-experts fp32 statement, gradients included
     (one expert receives no token at all in the small cases)."""
     from distributed_pytorch_amd import ops
@@ -461,9 +464,10 @@ def test_moe_topk_gate_matches_torch(N, E, k, with_bias):
     assert torch.allclose(lh.grad, lr.grad, atol=1e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize("block", [128, 256])
 @pytest.mark.parametrize("N,E,k", [(4096, 8, 2), (1000, 64, 8), (77, 3, 1), (65536, 8, 2), (5, 4, 2)])
-def test_moe_plan_matches_sort_based_layout(N, E, k):
-    """The histogram / scan / placement kernels produce exactly the stable-sort layout."""
+def test_moe_plan_matches_sort_based_layout(N, E, k, block):
+    """The histogram / scan / placement kernels produce exactly the stable-sort layout, for both row-block sizes."""
     from distributed_pytorch_amd.ops import moe
     ops = _ops()
     torch.manual_seed(0)
@@ -471,12 +475,12 @@ def test_moe_plan_matches_sort_based_layout(N, E, k):
     idx = idx.repeat((N + idx.shape[0] - 1) // idx.shape[0], 1)[:N].contiguous()
     if E > 2:
         idx[idx == E - 1] = 0                  # leave one expert empty
-    rows = moe.padded_rows(N * k, E)
-    got = ops.moe_plan(idx.reshape(-1), E, rows)
+    rows = moe.padded_rows(N * k, E, block)
+    got = ops.moe_plan(idx.reshape(-1), E, rows, block)
     import os
     os.environ["DPA_FORCE_EAGER"] = "1"
     try:
-        want = moe.plan(idx, E)
+        want = moe.plan(idx, E, block)
     finally:
         del os.environ["DPA_FORCE_EAGER"]
     assert torch.equal(got[0], want[0])                       # row_of_pair
@@ -978,3 +982,32 @@ def test_mlp_swiglu_fused_matches_unfused():
     for a, b, name in zip(got, [yr.detach(), xr.grad, fr.grad, pr.grad], ["y", "dx", "dw_fc", "dw_proj"]):
         err = ((a - b).norm() / b.norm()).item()
         assert err < 2e-2, f"{name}: relative error {err:.4f}"
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_nt_grouped_matches_per_block_reference(epi):
+    """Grouped mode of the NT GEMM: every 256-row block against its own weight matrix; a block without a
+    group gives zeros; GELU (+ derivative) and multiply epilogues."""
+    o = torch.ops.dpa
+    torch.manual_seed(epi)
+    G, N, K, nblk = 3, 384, 256, 7
+    rows = nblk * 256
+    a = torch.randn(rows, K, device="cuda").bfloat16()
+    ws = [(torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16() for _ in range(G)]
+    ptrs = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device="cuda")
+    groups = torch.tensor([0, 0, 2, 1, 3, 2, -1], dtype=torch.int32, device="cuda")     # 3 and -1: no group
+    aux = torch.randn(rows, N, device="cuda").bfloat16() if epi == 2 else None
+    c, extra = o.gemm_nt_grouped(a, ptrs, N, K, epi, aux, groups)
+    for b, g in enumerate(groups.tolist()):
+        blk = slice(256 * b, 256 * (b + 1))
+        v = a[blk].float() @ ws[g].float().t() if 0 <= g < G else torch.zeros(256, N, device="cuda")
+        if epi == 1:
+            want = torch.nn.functional.gelu(v)
+            vv = v.clone().requires_grad_()
+            torch.nn.functional.gelu(vv).sum().backward()
+            assert (extra[blk].float() - vv.grad).abs().max() <= 2e-2
+        elif epi == 2:
+            want = v * aux[blk].float()
+        else:
+            want = v
+        assert (c[blk].float() - want).abs().max() <= 2e-2 * want.abs().max() + 1e-3, (b, g)
