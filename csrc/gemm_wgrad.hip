@@ -227,11 +227,18 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
 // BIAS: the workgroups of the first K-tile column also sum their dY fragments over the tokens on the
 // otherwise idle VALU (each lane adds the 8 tokens of its column), giving the bias gradient
 // per split without a second pass over dY.
-template <bool ACCUM, bool BIAS>
-__global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+//
+// GROUPED: one product per row segment (the experts of a MoE layer in the padded expert-sorted layout), the
+// segment bounds read from device memory: workgroup = (segment, token split of that segment, output tile);
+// slab [split][segment][N][K]. An empty segment writes zeros.
+// (one wave per SIMD by construction — 128 KiB of LDS per workgroup —, stated to the register allocator so that all
+// 256 accumulators stay in AGPRs in every instantiation)
+template <bool ACCUM, bool BIAS, bool GROUPED = false>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad3_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                         float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                         int M, int N, int K, long long ldy, long long ldx,
-                                                        int splits, int mper) {
+                                                        int splits, int mper, const long long* __restrict__ seg_start = nullptr,
+                                                        const long long* __restrict__ seg_rows = nullptr, int nseg = 1) {
   constexpr int SUB = 64 * 128 * 2;  // 16 KiB
   constexpr int STAGE = 4 * SUB;     // 64 KiB: two dY sub-tiles + two X sub-tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,13 +250,25 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict
   // its own copy over the fabric (5-8 % on the GPT-2-124M shapes).
   const int ntile = (N / 256) * tiles_k;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = id / ntile, tile = id % ntile;
+  int split = id / ntile;
+  const int tile = id % ntile;
   const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
   const int wn = wave >> 1, wk = wave & 1;
-  const int m_begin = split * mper;
-  int m_end = m_begin + mper;
-  if (m_end > M) m_end = M;
+  int seg = 0, m_begin, m_end;
+  if (GROUPED) {
+    seg = split / splits;
+    split = split % splits;
+    const int base = (int)seg_start[seg], len = (int)seg_rows[seg];
+    const int per = (len / 64 + splits - 1) / splits * 64;
+    m_begin = base + split * per;
+    m_end = m_begin + per;
+    if (m_end > base + len) m_end = base + len;
+  } else {
+    m_begin = split * mper;
+    m_end = m_begin + mper;
+    if (m_end > M) m_end = M;
+  }
   const int ntiles = (m_end > m_begin) ? (m_end - m_begin) / 64 : 0;
 
   f32x16 acc[4][4];
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const bf16_t* __restrict
     }
   }
 
-  float* out = slabs + (ACCUM ? 0 : (long long)split * N * K);
+  float* out = slabs + (ACCUM ? 0 : ((long long)split * nseg + seg) * N * K);
   const int col = lane & 31;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -477,6 +496,31 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
   else
     hipLaunchKernelGGL((wgrad2_kernel<true>), grid, block, lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, M, N, K,
                        ldy, ldx, sp, mper);
+}
+
+int wgrad3_grouped_splits(long long rows, int nseg) {
+  // 4 splits of a segment give E * tiles * 4 workgroups (4.5 rounds of the chip for 8 experts of 3072 x 768) at
+  // half the slab traffic of 8; short segments get fewer so that a workgroup keeps at least 8 LDS tiles
+  const long long avg = rows / (nseg > 0 ? nseg : 1);
+  int s = (int)(avg / 512);
+  if (s > 4) s = 4;
+  return s < 1 ? 1 : s;
+}
+
+bool wgrad3_grouped_ok(long long rows, int N, int K) { return rows % 64 == 0 && rows > 0 && N % 256 == 0 && K % 256 == 0; }
+
+// ws: fp32 [splits, nseg, N, K] slabs (to be summed over the splits by wgrad_finish with n = nseg * N * K).
+void wgrad3_grouped(const void* dy, const void* x, float* ws, const long long* seg_start, const long long* seg_rows,
+                    int nseg, int rows, int N, int K, long long ldy, long long ldx, int splits, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              131072);
+    attr = true;
+  }
+  const dim3 grid((N / 256) * (K / 256) * splits * nseg), block(256);
+  hipLaunchKernelGGL((wgrad3_kernel<false, false, true>), grid, block, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws,
+                     (float*)nullptr, rows, N, K, ldy, ldx, splits, 0, seg_start, seg_rows, nseg);
 }
 
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,

@@ -200,6 +200,20 @@ def _direct_grad(p):
     return None
 
 
+_WGRAD3_SET = False
+
+
+def _grouped_wgrad(dy, x, seg_start, seg_rows):
+    """fp32 [E, N, K] per-expert weight gradients on the 128 x 128 grouped kernel; DPA_MOE_WGRAD3=1 sends the
+    shapes it takes to the grouped mode of the dense 256 x 256 kernel (faster only for long balanced segments)."""
+    global _WGRAD3_SET
+    if not _WGRAD3_SET:
+        _WGRAD3_SET = True
+        if os.environ.get("DPA_MOE_WGRAD3", "0") == "1" and hasattr(ops(), "grouped_wgrad_use_wgrad3"):
+            ops().grouped_wgrad_use_wgrad3(True)
+    return ops().grouped_wgrad(dy, x, seg_start, seg_rows)
+
+
 def _emit_wgrads(ws32, params, needs):
     """fp32 [E, N, K] gradients -> per-parameter results: accumulated straight into the engine's
     flat gradient buffer when the parameters ask for it (``_dpa_direct``; one launch for all
@@ -256,14 +270,14 @@ class _GroupedExpertsFn(torch.autograd.Function):
         a = _act_fwd(h, ctx.act)
         g_proj = [None] * E
         if any(needs[E:]):
-            g_proj = _emit_wgrads(ops().grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
+            g_proj = _emit_wgrads(_grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
         del a
         da = ops().grouped_gemm(dy, proj_ptrs, proj[0].shape[0], proj[0].shape[1], True, block_group)
         dh = _act_bwd(da, h, ctx.act)
         del da
         g_fc = [None] * E
         if any(needs[:E]):
-            g_fc = _emit_wgrads(ops().grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
+            g_fc = _emit_wgrads(_grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
         dx = None
         if ctx.needs_input_grad[0]:
             dxs = ops().grouped_gemm(dh, fc_ptrs, fc[0].shape[0], fc[0].shape[1], True, block_group)
@@ -322,13 +336,13 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
         dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
         g_proj = [None] * E
         if any(needs[E:]):
-            g_proj = _emit_wgrads(ops().grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
+            g_proj = _emit_wgrads(_grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
         # dh = (dy W_proj) * gelu'(h): NT on the per-step cached transposes, the multiply in the epilogue
         proj_t = [transposed_weight(w) for w in proj]          # [U, C] each
         dh = ops().gemm_nt_grouped(dy, _ptr_table(proj_t), U, C, 2, dact, block_group)[0]
         g_fc = [None] * E
         if any(needs[:E]):
-            g_fc = _emit_wgrads(ops().grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
+            g_fc = _emit_wgrads(_grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
         dx = None
         if ctx.needs_input_grad[0]:
             fc_t = [transposed_weight(w) for w in fc]          # [C, U] each
