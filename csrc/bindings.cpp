@@ -959,6 +959,28 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const
   return {c, aux_out};
 }
 
+// out[M, N] (rows of a larger buffer allowed: row stride >= N) = a[M, K] * b[N, K]^T, no epilogue.
+void gemm_nt_into(const Tensor& a, const Tensor& b, Tensor out) {
+  TORCH_CHECK(gemm_nt_supported(a, b, std::nullopt, std::nullopt), "gemm_nt_into: unsupported operands");
+  const int64_t M = a.size(0), N = b.size(0), K = a.size(1);
+  TORCH_CHECK(out.is_cuda() && out.scalar_type() == at::kBFloat16 && out.dim() == 2 && out.size(0) == M && out.size(1) == N &&
+                  out.stride(1) == 1 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0,
+              "gemm_nt_into: out is bf16 [M, N] with unit inner stride");
+  TORCH_CHECK(dpa::gemm_nt_ok(M, N, K, a.stride(0), b.stride(0), out.stride(0), 0, false), "gemm_nt_into: unsupported shape");
+  dpa::GemmNtArgs g{};
+  g.a = a.data_ptr();
+  g.b = b.data_ptr();
+  g.c = out.data_ptr();
+  g.M = (int)M;
+  g.N = (int)N;
+  g.K = (int)K;
+  g.lda = a.stride(0);
+  g.ldb = b.stride(0);
+  g.ldc = out.stride(0);
+  g.ld_aux = N;
+  dpa::gemm_nt(g, dpa::kEpiNone, gemm_cus(), cur_stream());
+}
+
 Tensor transpose_bf16(const Tensor& x) {
   TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.scalar_type() == at::kBFloat16 && x.is_contiguous() &&
                   x.size(0) % 8 == 0 && x.size(1) % 8 == 0 && reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
@@ -971,6 +993,7 @@ Tensor transpose_bf16(const Tensor& x) {
 TORCH_LIBRARY(dpa, m) {
   m.def("gemm_nt(Tensor a, Tensor b, Tensor? bias, int epi, Tensor? aux) -> (Tensor, Tensor?)");
   m.def("gemm_nt_supported(Tensor a, Tensor b, Tensor? bias, Tensor? aux) -> bool");
+  m.def("gemm_nt_into(Tensor a, Tensor b, Tensor(a!) out) -> ()");
   m.def("gemm_nt_grouped(Tensor a, Tensor w_ptrs, int n, int ldw, int epi, Tensor? aux, Tensor block_group) -> (Tensor, Tensor?)");
   m.def("gemm_nt_pair_supported(Tensor a, Tensor b, int epi, Tensor? aux) -> bool");
   m.def("gemm_nt_set_variant(int v) -> ()");
@@ -1035,6 +1058,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("ws_to_many", ws_to_many);
   m.impl("gemm_nt", gemm_nt);
+  m.impl("gemm_nt_into", gemm_nt_into);
   m.impl("gemm_nt_grouped", gemm_nt_grouped);
   m.impl("transpose_bf16", transpose_bf16);
   m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);

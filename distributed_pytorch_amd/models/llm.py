@@ -564,7 +564,7 @@ class LLM(nn.Module):
         self.apply(self._init_weights)
         self.VAL_RUN = False
         self.materialize_logits = False   # True: also return [B, T, V] logits when targets are given
-        self.loss_chunk_rows = int(os.environ.get("DPA_LOSS_CHUNK", "16384"))
+        self.loss_chunk_rows = int(os.environ.get("DPA_LOSS_CHUNK", "65536"))
         # set by a data-parallel engine built with vocab_parallel=True: (process group,) of the ranks the
         # vocabulary dimension of the head is split over during training
         self.vocab_parallel = None

@@ -10,11 +10,12 @@ MFMA kernel), the cross-entropy kernel (one read, one in-place write of the chun
 training) the two gradient GEMMs ``dx = dlogits @ w`` and ``dw += dlogits^T @ x`` run back to
 back on one reused bf16 buffer, so only ``[chunk, V]`` ever exists and the backward pass only
 rescales the stored gradients by the incoming scalar. The chunk is far larger than any cache of
-the part (16384 x 50304 bf16 = 1.6 GB): every pass over it is an HBM pass, and the chunk size
-is chosen for GEMM efficiency, not residency — measured per piece in benchmarks/lmhead_bench.py
-(2048-row chunks that would fit the 256 MB last-level cache cost 25 ms per 65536 rows against
-15.4 ms with 16384-row chunks: the dx product then has too few output tiles and the fp32 dW
-accumulator is re-read 32 times).
+the part (65536 x 50304 bf16 = 6.6 GB of the 288 GB): every pass over it is an HBM pass, and the
+chunk size is chosen for GEMM efficiency, not residency — measured per piece in
+benchmarks/lmhead_bench.py (2048-row chunks that would fit the 256 MB last-level cache cost 25 ms
+per 65536 rows against 15.4 ms with 16384-row chunks: the dx product then has too few output
+tiles and the fp32 dW accumulator is re-read 32 times; 65536-row chunks gain another 1 % of the
+step over 16384).
 
 ``vocab_parallel_cross_entropy``: the same loss with the vocabulary sharded over a process
 group (all-reduce of max / sum-exp / target logit between the two kernel halves).
@@ -77,10 +78,13 @@ def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int
     return F.cross_entropy(logits2.float(), targets1, ignore_index=ignore_index)
 
 
+_OWN_PIECE = 16384   # rows per launch of the own logits GEMM (16384 x 50304 bf16 = 1.6 GB, below its 2 GiB limit)
+
+
 def _own_logits_gemm(xc: torch.Tensor, w: torch.Tensor) -> bool:
     import os
     if os.environ.get("DPA_LIBRARY_GEMM", "0") == "1" or os.environ.get("DPA_LOSS_OWN_GEMM", "1") == "0" \
-            or not hasattr(ops(), "gemm_nt_supported"):
+            or not hasattr(ops(), "gemm_nt_into"):
         return False
     return bool(ops().gemm_nt_supported(xc, w, None, None))
 
@@ -102,19 +106,21 @@ class _LinearXentFn(torch.autograd.Function):
         nchunks = (N + chunk_rows - 1) // chunk_rows
         use_wg = need_dw and x.dtype == torch.bfloat16 and nchunks > 1
         ws = torch.zeros(V, C, dtype=torch.float32, device=x.device) if use_wg else None
-        own_gemm = x.dtype == torch.bfloat16 and _own_logits_gemm(x[: min(chunk_rows, N)], w)
-        logits = None if own_gemm else torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
-        lg = None
+        own_gemm = x.dtype == torch.bfloat16 and _own_logits_gemm(x[: min(_OWN_PIECE, N)], w)
+        logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
         for r0 in range(0, N, chunk_rows):
             r1 = min(N, r0 + chunk_rows)
             xc = x[r0:r1]
-            if own_gemm and ops().gemm_nt_supported(xc, w, None, None):
-                lg = None                                   # hand the previous chunk back before the next is made
-                lg = ops().gemm_nt(xc, w, None, 0, None)[0]
+            lg = logits[: r1 - r0]
+            if own_gemm:
+                # the own NT kernel addresses at most 2 GiB per operand: the chunk is filled in row pieces
+                for p0 in range(0, r1 - r0, _OWN_PIECE):
+                    p1 = min(r1 - r0, p0 + _OWN_PIECE)
+                    if ops().gemm_nt_supported(xc[p0:p1], w, None, None):
+                        ops().gemm_nt_into(xc[p0:p1], w, lg[p0:p1])
+                    else:
+                        torch.mm(xc[p0:p1], w.t(), out=lg[p0:p1])
             else:
-                if logits is None:
-                    logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
-                lg = logits[: r1 - r0]
                 torch.mm(xc, w.t(), out=lg)
             loss_rows = ops().xent_fused(lg, targets[r0:r1], gs, ignore_index, train)
             loss_acc += loss_rows.sum()
@@ -144,7 +150,7 @@ class _LinearXentFn(torch.autograd.Function):
 
 
 def linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor,
-                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 16384) -> torch.Tensor:
+                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 65536) -> torch.Tensor:
     """Mean cross-entropy of ``x @ w.T`` against ``targets`` (``x [N, C]``, ``w [V, C]``)."""
     x2 = x.reshape(-1, x.shape[-1])
     t1 = targets.reshape(-1)
