@@ -34,9 +34,9 @@ for pairs, N, K in ((32768, 3072, 768), (131072, 3072, 768), (131072, 768, 3072)
         ss, sr = start.cuda(), seg.cuda()
         flops = 2.0 * rows * N * K
         for on in (True, False):
-            o.grouped_wgrad_use_wgrad3(on)
+            o.grouped_wgrad_use_wgrad3(on, True)
             ms = timeit(lambda: o.grouped_wgrad(dy, x, ss, sr))
             print(f"rows {rows:>7} dW[{N},{K}] skew {skew}: {'256x256 grouped' if on else '128x128 grouped'} {ms * 1e3:8.1f} us "
                   f"{flops / ms / 1e9:7.0f} TF", flush=True)
         del dy, x
-o.grouped_wgrad_use_wgrad3(False)
+o.grouped_wgrad_use_wgrad3(True, False)

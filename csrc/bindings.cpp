@@ -608,11 +608,16 @@ Tensor grouped_gemm(const Tensor& a, const Tensor& w_ptrs, int64_t w_rows, int64
   return c;
 }
 
-// Off by default: 760 vs 941 us on balanced segments of 16384 rows, but equal or slower on skewed or short
-// segments (every segment gets the same number of token splits) and slower inside the MoE training step
-// (benchmarks/grouped_wgrad_bench.py); grouped_wgrad_use_wgrad3(true) / DPA_MOE_WGRAD3=1 turns it on.
-bool g_grouped_wgrad3 = false;
-void grouped_wgrad_use_wgrad3(bool on) { g_grouped_wgrad3 = on; }
+// The grouped mode of the dense 256 x 256 weight-gradient kernel takes over from 96 K rows on (24 chunks x 36 tiles
+// fill the chip several times over): 108 vs 110-113 ms per gpt-moe-8x step at micro-batch 64, where two of eight
+// experts can hold 90 % of the rows early in training; below that the 128 x 128 kernel's finer tiles win
+// (benchmarks/grouped_wgrad_bench.py). grouped_wgrad_use_wgrad3(false) / DPA_MOE_WGRAD3=0 turns it off.
+bool g_grouped_wgrad3 = true;
+bool g_grouped_wgrad3_any_size = false;   // tests: take the 256 x 256 kernel whatever the row count
+void grouped_wgrad_use_wgrad3(bool on, bool any_size) {
+  g_grouped_wgrad3 = on;
+  g_grouped_wgrad3_any_size = on && any_size;
+}
 
 // fp32 [G, N, K] = per-segment dy^T x.
 Tensor grouped_wgrad(const Tensor& dy, const Tensor& x, const Tensor& seg_start, const Tensor& seg_rows) {
@@ -624,16 +629,12 @@ Tensor grouped_wgrad(const Tensor& dy, const Tensor& x, const Tensor& seg_start,
                   seg_rows.is_cuda() && seg_rows.scalar_type() == at::kLong && seg_rows.is_contiguous() &&
                   seg_rows.numel() == G,
               "grouped_wgrad: segment tables are int64 cuda [G]");
-  if (dpa::wgrad3_grouped_ok(M, (int)N, (int)K) && g_grouped_wgrad3) {
-    // the dense layers' 256 x 256 kernel, one product per segment, fp32 slabs summed over the token splits
-    const int splits = dpa::wgrad3_grouped_splits(M, (int)G);
-    Tensor ws = at::empty({splits, G, N, K}, dy.options().dtype(at::kFloat));
-    dpa::wgrad3_grouped(dy.data_ptr(), x.data_ptr(), ws.data_ptr<float>(), (const long long*)seg_start.data_ptr<int64_t>(),
+  if (dpa::wgrad3_grouped_ok(M, (int)N, (int)K) && g_grouped_wgrad3 && (M >= 98304 || g_grouped_wgrad3_any_size)) {
+    // the dense layers' 256 x 256 kernel over equal row chunks of the segments, partial tiles added atomically
+    Tensor out = at::zeros({G, N, K}, dy.options().dtype(at::kFloat));
+    dpa::wgrad3_grouped(dy.data_ptr(), x.data_ptr(), out.data_ptr<float>(), (const long long*)seg_start.data_ptr<int64_t>(),
                         (const long long*)seg_rows.data_ptr<int64_t>(), (int)G, (int)M, (int)N, (int)K, dy.stride(0),
-                        x.stride(0), splits, cur_stream());
-    if (splits == 1) return ws.view({G, N, K});
-    Tensor out = at::empty({G, N, K}, dy.options().dtype(at::kFloat));
-    dpa::wgrad_finish(ws.data_ptr<float>(), out.data_ptr(), G * N * K, splits, false, false, cur_stream());
+                        x.stride(0), cur_stream());
     return out;
   }
   Tensor out = at::empty({G, N, K}, dy.options().dtype(at::kFloat));
@@ -997,7 +998,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("gemm_nt_grouped(Tensor a, Tensor w_ptrs, int n, int ldw, int epi, Tensor? aux, Tensor block_group) -> (Tensor, Tensor?)");
   m.def("gemm_nt_pair_supported(Tensor a, Tensor b, int epi, Tensor? aux) -> bool");
   m.def("gemm_nt_set_variant(int v) -> ()");
-  m.def("grouped_wgrad_use_wgrad3(bool on) -> ()");
+  m.def("grouped_wgrad_use_wgrad3(bool on, bool any_size=False) -> ()");
   m.def("transpose_bf16(Tensor x) -> Tensor");
   m.def("ws_to_many(Tensor ws, Tensor dst_ptrs, bool accumulate, bool out_bf16) -> ()");
   m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
@@ -1050,7 +1051,7 @@ TORCH_LIBRARY(dpa, m) {
 TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
   m.impl("wgrad2_set_stages", [](int64_t s) { dpa::wgrad2_set_stages((int)s); });
   m.impl("gemm_nt_set_variant", [](int64_t v) { dpa::gemm_nt_set_variant((int)v); });
-  m.impl("grouped_wgrad_use_wgrad3", [](bool on) { grouped_wgrad_use_wgrad3(on); });
+  m.impl("grouped_wgrad_use_wgrad3", [](bool on, bool any_size) { grouped_wgrad_use_wgrad3(on, any_size); });
   m.impl("gemm_nt_supported", gemm_nt_supported);
   m.impl("gemm_nt_pair_supported", gemm_nt_pair_supported);
 }

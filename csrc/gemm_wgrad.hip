@@ -229,8 +229,10 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
 // per split without a second pass over dY.
 //
 // GROUPED: one product per row segment (the experts of a MoE layer in the padded expert-sorted layout), the
-// segment bounds read from device memory: workgroup = (segment, token split of that segment, output tile);
-// slab [split][segment][N][K]. An empty segment writes zeros.
+// segment bounds read from device memory. Work item = (output tile, chunk of `mper` rows); the chunks are
+// numbered through the segments (segment s owns ceil(rows_s / mper) of them), so every workgroup has the same
+// amount of work whatever the routing did — early in training two of eight experts can hold 90 % of the rows.
+// Partial tiles are added into the zero-initialised fp32 [segments, N, K] result with float atomics.
 // (one wave per SIMD by construction — 128 KiB of LDS per workgroup —, stated to the register allocator so that all
 // 256 accumulators stay in AGPRs in every instantiation)
 template <bool ACCUM, bool BIAS, bool GROUPED = false>
@@ -257,13 +259,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   const int wn = wave >> 1, wk = wave & 1;
   int seg = 0, m_begin, m_end;
   if (GROUPED) {
-    seg = split / splits;
-    split = split % splits;
-    const int base = (int)seg_start[seg], len = (int)seg_rows[seg];
-    const int per = (len / 64 + splits - 1) / splits * 64;
-    m_begin = base + split * per;
-    m_end = m_begin + per;
+    int c = split, len = 0;
+    for (seg = 0; seg < nseg; ++seg) {
+      len = (int)seg_rows[seg];
+      const int nch = (len + mper - 1) / mper;
+      if (c < nch) break;
+      c -= nch;
+    }
+    if (seg == nseg) return;   // past the last chunk (the grid is sized for the worst case)
+    const int base = (int)seg_start[seg];
+    m_begin = base + c * mper;
+    m_end = m_begin + mper;
     if (m_end > base + len) m_end = base + len;
+    split = 0;
   } else {
     m_begin = split * mper;
     m_end = m_begin + mper;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
   }
 
-  float* out = slabs + (ACCUM ? 0 : ((long long)split * nseg + seg) * N * K);
+  float* out = slabs + (GROUPED ? (long long)seg * N * K : (ACCUM ? 0 : (long long)split * N * K));
   const int col = lane & 31;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -340,7 +348,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + 128 * wn + 32 * i + acc_row(r, hh);
         float* p = out + (long long)n * K + kk;
-        if (ACCUM) *p += acc[i][j][r];
+        if (GROUPED) unsafeAtomicAdd(p, acc[i][j][r]);
+        else if (ACCUM) *p += acc[i][j][r];
         else *p = acc[i][j][r];
       }
     }
@@ -498,29 +507,23 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
                        ldy, ldx, sp, mper);
 }
 
-int wgrad3_grouped_splits(long long rows, int nseg) {
-  // 4 splits of a segment give E * tiles * 4 workgroups (4.5 rounds of the chip for 8 experts of 3072 x 768) at
-  // half the slab traffic of 8; short segments get fewer so that a workgroup keeps at least 8 LDS tiles
-  const long long avg = rows / (nseg > 0 ? nseg : 1);
-  int s = (int)(avg / 512);
-  if (s > 4) s = 4;
-  return s < 1 ? 1 : s;
-}
+constexpr int kGroupedChunk = 4096;   // rows per work item: 64 LDS tiles, ~130 us; 256 KiB of atomics per item
 
 bool wgrad3_grouped_ok(long long rows, int N, int K) { return rows % 64 == 0 && rows > 0 && N % 256 == 0 && K % 256 == 0; }
 
-// ws: fp32 [splits, nseg, N, K] slabs (to be summed over the splits by wgrad_finish with n = nseg * N * K).
-void wgrad3_grouped(const void* dy, const void* x, float* ws, const long long* seg_start, const long long* seg_rows,
-                    int nseg, int rows, int N, int K, long long ldy, long long ldx, int splits, hipStream_t st) {
+// out: fp32 [nseg, N, K], zero-initialised by the caller.
+void wgrad3_grouped(const void* dy, const void* x, float* out, const long long* seg_start, const long long* seg_rows,
+                    int nseg, int rows, int N, int K, long long ldy, long long ldx, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               131072);
     attr = true;
   }
-  const dim3 grid((N / 256) * (K / 256) * splits * nseg), block(256);
-  hipLaunchKernelGGL((wgrad3_kernel<false, false, true>), grid, block, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws,
-                     (float*)nullptr, rows, N, K, ldy, ldx, splits, 0, seg_start, seg_rows, nseg);
+  const int max_chunks = rows / kGroupedChunk + nseg;
+  const dim3 grid((N / 256) * (K / 256) * max_chunks), block(256);
+  hipLaunchKernelGGL((wgrad3_kernel<false, false, true>), grid, block, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, out,
+                     (float*)nullptr, rows, N, K, ldy, ldx, 1, kGroupedChunk, seg_start, seg_rows, nseg);
 }
 
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,

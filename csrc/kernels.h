@@ -99,12 +99,12 @@ void wgrad2_set_stages(int s);
 // bias_slabs (optional, only when wgrad2_fuses_bias(M, N, K) and splits > 0): fp32 [splits, N] receiving the
 // per-split column sums of dy (the bias gradient), produced inside the same kernel.
 bool wgrad2_fuses_bias(int M, int N, int K);
-// Per-segment weight gradients on the 256 x 256 kernel (segment bounds in device memory, multiples of 64 rows):
-// ws = fp32 [splits, nseg, N, K] slabs, summed over the splits by wgrad_finish. N % 256 == 0, K % 256 == 0.
-int wgrad3_grouped_splits(long long rows, int nseg);
+// Per-segment weight gradients on the 256 x 256 kernel (segment bounds in device memory, multiples of 64 rows),
+// work divided in equal row chunks across the segments: out = fp32 [nseg, N, K], zero-initialised by the caller,
+// receives the partial tiles through float atomics. N % 256 == 0, K % 256 == 0.
 bool wgrad3_grouped_ok(long long rows, int N, int K);
-void wgrad3_grouped(const void* dy, const void* x, float* ws, const long long* seg_start, const long long* seg_rows,
-                    int nseg, int rows, int N, int K, long long ldy, long long ldx, int splits, hipStream_t st);
+void wgrad3_grouped(const void* dy, const void* x, float* out, const long long* seg_start, const long long* seg_rows,
+                    int nseg, int rows, int N, int K, long long ldy, long long ldx, hipStream_t st);
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
                  int splits, hipStream_t st, float* bias_slabs = nullptr);
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,

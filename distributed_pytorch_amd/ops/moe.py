@@ -204,13 +204,17 @@ _WGRAD3_SET = False
 
 
 def _grouped_wgrad(dy, x, seg_start, seg_rows):
-    """fp32 [E, N, K] per-expert weight gradients on the 128 x 128 grouped kernel; DPA_MOE_WGRAD3=1 sends the
-    shapes it takes to the grouped mode of the dense 256 x 256 kernel (faster only for long balanced segments)."""
+    """fp32 [E, N, K] per-expert weight gradients: from 96 K rows on the grouped mode of the dense 256 x 256 kernel
+    (equal row chunks across the segments, atomically combined), below that the 128 x 128 grouped kernel.
+    DPA_MOE_WGRAD3=0 keeps the latter everywhere (A/B runs)."""
     global _WGRAD3_SET
     if not _WGRAD3_SET:
         _WGRAD3_SET = True
-        if os.environ.get("DPA_MOE_WGRAD3", "0") == "1" and hasattr(ops(), "grouped_wgrad_use_wgrad3"):
-            ops().grouped_wgrad_use_wgrad3(True)
+        if os.environ.get("DPA_MOE_WGRAD3", "1") == "0" and hasattr(ops(), "grouped_wgrad_use_wgrad3"):
+            ops().grouped_wgrad_use_wgrad3(False)
+    if os.environ.get("DPA_DEBUG_SEG") == "1":     # debugging aid (host read): the segment table of this call
+        print("grouped_wgrad", tuple(dy.shape), tuple(x.shape), dy.stride(), x.stride(), seg_start.tolist(), seg_rows.tolist(),
+              flush=True)
     return ops().grouped_wgrad(dy, x, seg_start, seg_rows)
 
 

@@ -1014,20 +1014,20 @@ def test_gemm_nt_grouped_matches_per_block_reference(epi):
 
 
 def test_grouped_wgrad_on_the_256_kernel_matches():
-    """Opt-in grouped mode of the dense 256 x 256 weight-gradient kernel: per-segment dy^T x with an empty and
-    a short segment, against fp32."""
+    """Grouped mode of the dense 256 x 256 weight-gradient kernel (equal row chunks over the segments, combined
+    atomically): per-segment dy^T x with an empty, a short and a multi-chunk segment, against fp32."""
     o = torch.ops.dpa
     torch.manual_seed(5)
-    seg = torch.tensor([1024, 0, 256, 2048], dtype=torch.int64)
+    seg = torch.tensor([1024, 0, 256, 9216], dtype=torch.int64)
     start = torch.cumsum(seg, 0) - seg
     rows, N, K = int(seg.sum()) + 256, 512, 256          # 256 trailing padding rows belong to no segment
     dy = torch.randn(rows, N, device="cuda").bfloat16()
     x = torch.randn(rows, K, device="cuda").bfloat16()
-    o.grouped_wgrad_use_wgrad3(True)
+    o.grouped_wgrad_use_wgrad3(True, True)      # second flag: whatever the row count
     try:
         got = o.grouped_wgrad(dy, x, start.cuda(), seg.cuda())
     finally:
-        o.grouped_wgrad_use_wgrad3(False)
+        o.grouped_wgrad_use_wgrad3(True, False)
     for g in range(4):
         s, n = int(start[g]), int(seg[g])
         want = dy[s:s + n].float().t() @ x[s:s + n].float()
