@@ -63,6 +63,25 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
+
+// Max / sum of x over the two lanes 32 apart, in both (v_permlane32_swap: a register exchange between the
+// wave's halves, no trip through LDS as __shfl_xor takes). After swapping the upper half of one copy with the
+// lower half of the other, one copy holds the lower half's x in both halves and the other the upper half's.
+// Issued from assembly: with the same value as both operands of the builtin the compiler folds the two
+// results into one.
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float max_halves(float x) {
+  float a = x, b = x;
+  swap_halves(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float sum_halves(float x) {
+  float a = x, b = x;
+  swap_halves(a, b);
+  return a + b;
+}
 constexpr float kDefer = 6.0f;   // deferred-rescale threshold of the forward, in log2 units
 
 // Dropout mask: keep(q, k) for one (batch, head) is a 32-bit mix of the pair's index with a per-head
@@ -109,13 +128,108 @@ __device__ __forceinline__ void tile_order(int bid, int nwg, int ntile, int BH, 
 }
 
 // ------------------------------------------------------------------------------------------
+// [64][HS] operand tiles by LDS-DMA (buffer_load ... lds): no staging registers, no address or
+// zero-fill arithmetic in the tile loop. A piece is the 1 KiB one wave instruction moves (64 lanes x 16
+// bytes, contiguous in LDS); the XOR swizzle of the tile image is applied on the global side, the
+// per-tile advance is the instruction's scalar offset. Issued from assembly: the compiler would drain
+// an LDS-DMA builtin (vmcnt(0)) before the next LDS read, i.e. right after issuing it.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* ptr) {
+  const unsigned long long a = (unsigned long long)ptr;
+  rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  r[2] = 0xffffffffu;   // no range check: rows past the end are redirected by the caller
+  r[3] = 0x00020000u;
+  return r;
+}
+
+__device__ __forceinline__ void dma_piece(unsigned lds_addr, unsigned voff, rsrc_t rs, unsigned soff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+}
+
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int HS>
+struct TileDma {
+  static constexpr int CPR = HS / 8;        // 16-byte chunks per row
+  static constexpr int RPP = 64 / CPR;      // rows per piece
+  static constexpr int NP = 64 / RPP / 4;   // pieces per wave
+  unsigned voff[NP];                        // this lane's source byte offset inside a tile, by piece
+  unsigned ts2;                             // row stride in bytes
+  int wave, lane;
+  __device__ __forceinline__ void init(long long ts, int wave_, int lane_) {
+    ts2 = (unsigned)(ts * 2);
+    wave = wave_;
+    lane = lane_;
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+      const int row = (wave * NP + pc) * RPP + lane / CPR;
+      voff[pc] = row * ts2 + 16 * swz<HS>(row, lane % CPR);
+    }
+  }
+  // Rows [row0, row0 + 64) of the matrix behind `rs` -> tile at LDS address `lds`. Rows at or past
+  // `nrows` re-read row `row0` (finite values; whatever is computed from them is masked).
+  __device__ __forceinline__ void issue(rsrc_t rs, int row0, int nrows, unsigned lds) const {
+    const unsigned soff = __builtin_amdgcn_readfirstlane(row0 * ts2);
+    if (row0 + 64 <= nrows) {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) dma_piece(lds + (wave * NP + pc) * 1024, voff[pc], rs, soff);
+    } else {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) {
+        const int row = (wave * NP + pc) * RPP + lane / CPR;
+        const unsigned v = (row0 + row < nrows) ? voff[pc] : 16u * swz<HS>(row, lane % CPR);
+        dma_piece(lds + (wave * NP + pc) * 1024, v, rs, soff);
+      }
+    }
+  }
+};
+
+// 8 bf16 of a row, times c, as an MFMA operand.
+__device__ __forceinline__ bfrag scaled_frag(const bf16_t* src, float c) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(lo_bf16(v[j]) * c, hi_bf16(v[j]) * c);
+  return __builtin_bit_cast(bfrag, o);
+}
+
+// Sums of probabilities a tile may reach before the running reference point of its rows is moved, and the
+// least sum the first tile must reach for the initial reference (0) to be kept.
+constexpr float kSumHi = 1.0e9f, kSumLo = 1.0e-9f;
+
+// ------------------------------------------------------------------------------------------
 // Forward
+//
+// Softmax bookkeeping. Q is multiplied by scale * log2(e) once, when its fragments are loaded, and the
+// score MFMA chain starts from an accumulator that holds -m (m = the row's reference point in log2
+// units), so the chain's result is already the argument of exp2: a score costs one v_exp, one add for
+// the row sum and half a convert. No row maximum is taken on the normal path. m starts at 0 and stays
+// until a tile's probabilities sum past kSumHi for some row (or the first tile's stay below kSumLo);
+// that tile is then redone the classic way: raw scores, row maximum, O and l rescaled to the new m.
+// Probabilities up to ~1e9 instead of <= 1 cost nothing in accuracy: fp32 sums and the bf16 P operand
+// have the same relative precision at any magnitude.
 // ------------------------------------------------------------------------------------------
 template <int HS, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
+  constexpr int KSUB = HS == 64 ? 2 : 1;   // 32-key sub-tiles whose fragments are in registers together
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
   const int BH = p.B * p.nh;
   const int nqt = (p.Tq + 127) / 128;
   int rank, bh;
@@ -129,117 +243,168 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
   const int q0 = qt * 128, off = Tk - p.Tq;
   const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
-  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
-  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
-
-  const int qrow = q0 + wave * 32 + r;
-  bfrag qf[NK];
-#pragma unroll
-  for (int ks = 0; ks < NK; ++ks) {
-    qf[ks] = zero_frag();
-    if (qrow < p.Tq) qf[ks] = *reinterpret_cast<const bfrag*>(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8);
-  }
+  const rsrc_t krs = make_rsrc((const bf16_t*)p.k + b * p.k_bs + kvh * HS);
+  const rsrc_t vrs = make_rsrc((const bf16_t*)p.v + b * p.v_bs + kvh * HS);
 
   int kv_end = q0 + 128 + off;
   if (kv_end > Tk) kv_end = Tk;
   const int ntiles = (kv_end + 63) / 64;
   const int wave_qmax = q0 + wave * 32 + 31;
 
-  Stage64<HS> ks_, vs_;
-  ks_.issue(kp, 0, Tk, p.k_ts, tid);
-  vs_.issue(vp, 0, Tk, p.v_ts, tid);
-  ks_.commit(smem, tid);
-  vs_.commit(smem + TILE, tid);
+  TileDma<HS> kd, vd;
+  kd.init(p.k_ts, wave, lane);
+  vd.init(p.v_ts, wave, lane);
+  kd.issue(krs, 0, Tk, lds0);
+  vd.issue(vrs, 0, Tk, lds0 + TILE);
 
-  f32x16 oacc[ND];
+  const float c = p.scale * kLog2e;
+  const int qrow = q0 + wave * 32 + r;
+  bfrag qf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = zero_frag();
+    if (qrow < p.Tq) qf[ks] = scaled_frag(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8, c);
+  }
+
+  f32x16 oacc[ND], negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 #pragma unroll
   for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  const float c = p.scale * kLog2e;
+  float m = 0.f, l = 0.f;   // m in log2 units
   int qlim = qrow + off;
   if (qlim > Tk - 1) qlim = Tk - 1;
   const unsigned dkey = DROP ? drop_key(p.seed, bh) : 0u, dthr = DROP ? drop_threshold(p.p_drop) : 0u;
 
   for (int t = 0; t < ntiles; ++t) {
+    wait_dma();
+    __syncthreads();   // tile t has landed for every wave; every wave is done with tile t - 1's buffer
     if (t + 1 < ntiles) {
-      ks_.issue(kp, (t + 1) * 64, Tk, p.k_ts, tid);
-      vs_.issue(vp, (t + 1) * 64, Tk, p.v_ts, tid);
+      const unsigned nb = lds0 + ((t + 1) & 1) * 2 * TILE;
+      kd.issue(krs, (t + 1) * 64, Tk, nb);
+      vd.issue(vrs, (t + 1) * 64, Tk, nb + TILE);
     }
-    __syncthreads();
     const char* kb = smem + (t & 1) * 2 * TILE;
     const char* vb = kb + TILE;
     const int kv0 = t * 64;
     if (kv0 <= wave_qmax + off) {  // wave-uniform: some key of this tile is visible to the wave
-      f32x16 s[2];
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) s[sub] = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s[sub]);
-      }
       const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > Tk);
-      if (need_mask) {
+      // s = scores - m, from the accumulator `init`. LDS reads go out in batches ahead of their products
+      // (all K fragments before the first MFMA): a read issued right before its MFMA, which is the
+      // compiler's pressure-minimising order, exposes the LDS latency once per MFMA.
+      f32x16 s[2];
+      auto scores = [&](const f32x16& init) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sb = 0; sb < 2; sb += KSUB) {
+          bfrag kf[KSUB][NK];
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (kv0 + sub * 32 + acc_row(i, hh) > qlim) s[sub][i] = -INFINITY;
-      }
-      float mx = s[0][0];
+          for (int u = 0; u < KSUB; ++u)
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+            for (int ks = 0; ks < NK; ++ks) kf[u][ks] = row_frag<HS>(kb, (sb + u) * 32 + r, ks, hh);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[sub][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // Deferred rescale: the running maximum only moves (and O, l are only rescaled) when some
-      // row's tile maximum exceeds it by more than kDefer in the exponent; until then the
-      // probabilities are bounded by 2^kDefer instead of 1, which fp32 accumulation and the
-      // bf16 P operand (same relative precision at any magnitude) absorb. The decision is
-      // wave-uniform, taken before this tile's P is formed and after the previous tile's P*V
-      // has been issued, so everything at the old scale is rescaled exactly once.
-      if (!__all((mx - m) * c <= kDefer)) {
-        const float m_new = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-        l *= alpha;
-        m = m_new;
+          for (int u = 0; u < KSUB; ++u) {
+            s[sb + u] = mfma32(kf[u][0], qf[0], init);
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
+            for (int ks = 1; ks < NK; ++ks) s[sb + u] = mfma32(kf[u][ks], qf[ks], s[sb + u]);
+          }
+        }
+        if (need_mask) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
-      }
-      const float mc = m * c;
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              if (kv0 + sub * 32 + acc_row(i, hh) > qlim) s[sub][i] = -INFINITY;
+        }
+      };
+      scores(negm);
+      bfrag vf[KSUB][2][ND];
+#pragma unroll
+      for (int u = 0; u < KSUB; ++u)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<HS>(vb, u * 32, s2, dt, lane);
+      __builtin_amdgcn_sched_barrier(0);
       float rs = 0.f;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][i], c, -mc));
-          rs += pv;   // the softmax normaliser is that of the undropped row
-          s[sub][i] = (DROP && !drop_keep(dkey, qrow, kv0 + sub * 32 + acc_row(i, hh), dthr)) ? 0.f : pv;
+          s[sub][i] = __builtin_amdgcn_exp2f(s[sub][i]);
+          rs += s[sub][i];
         }
-      l += rs;
+      bool redo = !__all(rs <= kSumHi);
+      if (t == 0) redo = redo || !__all(sum_halves(rs) >= kSumLo);
+      if (redo) {
+        f32x16 zero;
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+        for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+        scores(zero);
+        float mx = s[0][0];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bfrag pb = acc_frag(s[sub], s2);
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-          for (int dt = 0; dt < ND; ++dt) oacc[dt] = mfma32(tr_frag<HS>(vb, sub * 32, s2, dt, lane), pb, oacc[dt]);
+          for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[sub][i]);
+        mx = max_halves(mx);
+        // The first tile replaces the initial guess outright (O and l are still zero); later the
+        // reference only moves up, and what was accumulated at the old one is rescaled.
+        const float m_new = t == 0 ? mx : fmaxf(m, mx);
+        const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = -m_new;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+        rs = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            s[sub][i] = __builtin_amdgcn_exp2f(s[sub][i] - m_new);
+            rs += s[sub][i];
+          }
+      }
+      l += rs;   // the softmax normaliser is that of the undropped row
+      if (DROP) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (!drop_keep(dkey, qrow, kv0 + sub * 32 + acc_row(i, hh), dthr)) s[sub][i] = 0.f;
+      }
+#pragma unroll
+      for (int sb = 0; sb < 2; sb += KSUB) {
+        if (sb > 0) {
+#pragma unroll
+          for (int u = 0; u < KSUB; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<HS>(vb, (sb + u) * 32, s2, dt, lane);
+          __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    if (t + 1 < ntiles) {
-      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
-      ks_.commit(nb, tid);
-      vs_.commit(nb + TILE, tid);
+#pragma unroll
+        for (int u = 0; u < KSUB; ++u)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bfrag pb = acc_frag(s[sb + u], s2);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) oacc[dt] = mfma32(vf[u][s2][dt], pb, oacc[dt]);
+          }
+      }
     }
   }
 
-  l += __shfl_xor(l, 32, 64);
+  l = sum_halves(l);
   const float inv = (DROP ? 1.f / (1.f - p.p_drop) : 1.f) / l;
-  if (hh == 0 && qrow < p.Tq) p.lse[((long long)b * p.nh + h) * p.Tq + qrow] = m * p.scale + __logf(l);
+  if (hh == 0 && qrow < p.Tq)
+    p.lse[((long long)b * p.nh + h) * p.Tq + qrow] = (m + __builtin_amdgcn_logf(l)) * (1.f / kLog2e);
   __syncthreads();  // all waves are done with the K/V tiles before the region is reused
   bf16_t* op = (bf16_t*)p.o + b * p.o_bs + h * HS;
   store_tile_T<HS>(smem + wave * 32 * HS * 2, oacc, inv, op, p.o_ts, q0 + wave * 32, p.Tq, lane);
@@ -288,7 +453,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
     lse2 = p.lse[((long long)b * p.nh + h) * p.Tq + qrow] * kLog2e;
   }
-  dlt += __shfl_xor(dlt, 32, 64);
+  dlt = sum_halves(dlt);
   if (hh == 0 && qrow < p.Tq) p.delta[((long long)b * p.nh + h) * p.Tq + qrow] = dlt;
 
   int kv_end = q0 + 128 + off;
