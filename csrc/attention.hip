@@ -411,13 +411,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward, dQ: one workgroup = 128 queries, sweeps the keys. Also writes delta[b, h, q] = sum_d dO * O.
+// Backward. P is recomputed from the forward's log-sum-exp; the row constants ride in the MFMA
+// chains' initial accumulators: S' = (c q) k - lse * log2(e) makes p = exp2(S') one instruction, and
+// dP' = dO v - delta makes dS = p * dP' one multiply. The operand a wave keeps in registers for the
+// whole kernel (Q in the dQ kernel, K in the dK/dV kernel) carries c = scale * log2(e).
+//
+// The dQ kernel runs first and publishes the row constants for the dK/dV kernel in `stats`
+// ([2][B * nh][Tq rounded up to 128] floats): -delta (delta = rowsum(dO * O)) and -lse * log2(e), with
+// 0 / -inf in the rows past Tq, so that the dK/dV kernel moves them into LDS by DMA as they are.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int stat_rows(int Tq) { return (Tq + 127) / 128 * 128; }
+
+// 64 floats (one per lane) from rs[voff + soff] to LDS [lds_addr, lds_addr + 256).
+__device__ __forceinline__ void dma_dwords(unsigned lds_addr, unsigned voff, rsrc_t rs, unsigned soff) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dword %2, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+}
+
+// dQ: one workgroup = 128 queries, sweeps the keys.
 template <int HS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
   const int BH = p.B * p.nh;
   const int nqt = (p.Tq + 127) / 128;
   int rank, bh;
@@ -427,107 +453,124 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int q0 = qt * 128, off = p.Tk - p.Tq;
   const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
   const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + h * HS;
-  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
-  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
-
-  const int qrow = q0 + wave * 32 + r;
-  bfrag qf[NK], dof[NK];
-  float lse2 = INFINITY, dlt = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < NK; ++ks) {
-    qf[ks] = zero_frag();
-    dof[ks] = zero_frag();
-  }
-  if (qrow < p.Tq) {
-    // delta = rowsum(dO * O) is formed here from the dO fragments the kernel holds anyway (each lane
-    // half owns half of the row) and published for the dK/dV kernel, which runs afterwards.
-    const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * HS + (long long)qrow * p.o_ts;
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      qf[ks] = *reinterpret_cast<const bfrag*>(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8);
-      dof[ks] = *reinterpret_cast<const bfrag*>(dop + (long long)qrow * p.do_ts + ks * 16 + hh * 8);
-      const u32x4 ov = *reinterpret_cast<const u32x4*>(orow + ks * 16 + hh * 8);
-      const u32x4 dv = __builtin_bit_cast(u32x4, dof[ks]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dlt += lo_bf16(ov[j]) * lo_bf16(dv[j]) + hi_bf16(ov[j]) * hi_bf16(dv[j]);
-    }
-    lse2 = p.lse[((long long)b * p.nh + h) * p.Tq + qrow] * kLog2e;
-  }
-  dlt = sum_halves(dlt);
-  if (hh == 0 && qrow < p.Tq) p.delta[((long long)b * p.nh + h) * p.Tq + qrow] = dlt;
+  const rsrc_t krs = make_rsrc((const bf16_t*)p.k + b * p.k_bs + kvh * HS);
+  const rsrc_t vrs = make_rsrc((const bf16_t*)p.v + b * p.v_bs + kvh * HS);
 
   int kv_end = q0 + 128 + off;
   if (kv_end > p.Tk) kv_end = p.Tk;
   const int ntiles = (kv_end + 63) / 64;
   const int wave_qmax = q0 + wave * 32 + 31;
 
-  Stage64<HS> ks_, vs_;
-  ks_.issue(kp, 0, p.Tk, p.k_ts, tid);
-  vs_.issue(vp, 0, p.Tk, p.v_ts, tid);
-  ks_.commit(smem, tid);
-  vs_.commit(smem + TILE, tid);
+  TileDma<HS> kd, vd;
+  kd.init(p.k_ts, wave, lane);
+  vd.init(p.v_ts, wave, lane);
+  kd.issue(krs, 0, p.Tk, lds0);
+  vd.issue(vrs, 0, p.Tk, lds0 + TILE);
+
+  const float c = p.scale * kLog2e;
+  const int qrow = q0 + wave * 32 + r;
+  bfrag qf[NK], dof[NK];
+  float nlse = -INFINITY, dlt = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    qf[ks] = zero_frag();
+    dof[ks] = zero_frag();
+  }
+  if (qrow < p.Tq) {
+    // delta = rowsum(dO * O) from the dO fragments the kernel holds anyway (each lane half owns half
+    // of the row).
+    const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * HS + (long long)qrow * p.o_ts;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      qf[ks] = scaled_frag(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8, c);
+      dof[ks] = *reinterpret_cast<const bfrag*>(dop + (long long)qrow * p.do_ts + ks * 16 + hh * 8);
+      const u32x4 ov = *reinterpret_cast<const u32x4*>(orow + ks * 16 + hh * 8);
+      const u32x4 dv = __builtin_bit_cast(u32x4, dof[ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dlt += lo_bf16(ov[j]) * lo_bf16(dv[j]) + hi_bf16(ov[j]) * hi_bf16(dv[j]);
+    }
+    nlse = -p.lse[((long long)b * p.nh + h) * p.Tq + qrow] * kLog2e;
+  }
+  dlt = sum_halves(dlt);
+  if (hh == 0) {   // every row of the tile, the padding past Tq included
+    const long long srow = (long long)bh * stat_rows(p.Tq) + qrow;
+    p.delta[srow] = -dlt;
+    p.delta[(long long)BH * stat_rows(p.Tq) + srow] = nlse;
+  }
+  f32x16 negl, negd;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    negl[i] = nlse;
+    negd[i] = -dlt;
+  }
 
   f32x16 dqacc[ND];
 #pragma unroll
   for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) dqacc[dt][i] = 0.f;
-  const float c = p.scale * kLog2e;
   int qlim = qrow + off;
   if (qlim > p.Tk - 1) qlim = p.Tk - 1;
   const unsigned dkey = DROP ? drop_key(p.seed, bh) : 0u, dthr = DROP ? drop_threshold(p.p_drop) : 0u;
   const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
 
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) {
-      ks_.issue(kp, (t + 1) * 64, p.Tk, p.k_ts, tid);
-      vs_.issue(vp, (t + 1) * 64, p.Tk, p.v_ts, tid);
-    }
+    wait_dma();
     __syncthreads();
+    if (t + 1 < ntiles) {
+      const unsigned nb = lds0 + ((t + 1) & 1) * 2 * TILE;
+      kd.issue(krs, (t + 1) * 64, p.Tk, nb);
+      vd.issue(vrs, (t + 1) * 64, p.Tk, nb + TILE);
+    }
     const char* kb = smem + (t & 1) * 2 * TILE;
     const char* vb = kb + TILE;
     const int kv0 = t * 64;
-    if (kv0 <= wave_qmax + off) {
-      const bool need_mask = (kv0 + 63 > q0 + wave * 32 + off) || (kv0 + 64 > p.Tk);
-      // The masked form (compare + select per score) only runs on tiles the diagonal crosses.
-      auto tile = [&](auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
+    const int wq0 = q0 + wave * 32 + off;
+    // 32-key sub-tiles with a key visible to the wave. A rolled loop: with one `if` per unrolled
+    // sub-tile the compiler copies all the dQ accumulators at every join.
+    const int nsub = kv0 > wave_qmax + off ? 0 : (kv0 + 32 > wave_qmax + off ? 1 : 2);
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+      const int ks0 = kv0 + sub * 32;
+      const char* ksub = kb + sub * (32 * HS * 2);
+      const char* vsub = vb + sub * (32 * HS * 2);
+      bfrag kf[NK], vf[NK];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-          f32x16 s, dp;
+      for (int ks = 0; ks < NK; ++ks) kf[ks] = row_frag<HS>(ksub, r, ks, hh);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            s[i] = 0.f;
-            dp[i] = 0.f;
-          }
+      for (int ks = 0; ks < NK; ++ks) vf[ks] = row_frag<HS>(vsub, r, ks, hh);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 s = mfma32(kf[0], qf[0], negl), dp = mfma32(vf[0], dof[0], negd);
 #pragma unroll
-          for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(kb, sub * 32 + r, ks, hh), qf[ks], s);
+      for (int ks = 1; ks < NK; ++ks) s = mfma32(kf[ks], qf[ks], s);
 #pragma unroll
-          for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(vb, sub * 32 + r, ks, hh), dof[ks], dp);
+      for (int ks = 1; ks < NK; ++ks) dp = mfma32(vf[ks], dof[ks], dp);
+      bfrag kt[2][ND];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -lse2));
-            if (MASK && (kv0 + sub * 32 + acc_row(i, hh) > qlim)) pv = 0.f;
-            float dpi = dp[i];
-            if (DROP) dpi = drop_keep(dkey, qrow, kv0 + sub * 32 + acc_row(i, hh), dthr) ? dpi * rkeep : 0.f;
-            s[i] = pv * (dpi - dlt);  // dS^T
-          }
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const bfrag dsb = acc_frag(s, s2);
+        for (int dt = 0; dt < ND; ++dt) kt[s2][dt] = tr_frag<HS>(ksub, 0, s2, dt, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      // compare + select only where the diagonal or the end of the keys crosses the sub-tile
+      if ((ks0 + 31 > wq0) || (ks0 + 32 > p.Tk)) {
 #pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-              dqacc[dt] = mfma32(tr_frag<HS>(kb, sub * 32, s2, dt, lane), dsb, dqacc[dt]);
-          }
-        }
-      };
-      if (need_mask) tile(std::true_type{});
-      else tile(std::false_type{});
-    }
-    if (t + 1 < ntiles) {
-      char* nb = smem + ((t + 1) & 1) * 2 * TILE;
-      ks_.commit(nb, tid);
-      vs_.commit(nb + TILE, tid);
+        for (int i = 0; i < 16; ++i)
+          if (ks0 + acc_row(i, hh) > qlim) s[i] = -INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(s[i]);
+        float dpi = dp[i];
+        // dropped pairs: dP = 0 before delta is taken off, i.e. dS = -p * delta
+        if (DROP) dpi = drop_keep(dkey, qrow, ks0 + acc_row(i, hh), dthr) ? (dpi + dlt) * rkeep - dlt : -dlt;
+        s[i] = pv * dpi;  // dS^T
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bfrag dsb = acc_frag(s, s2);
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) dqacc[dt] = mfma32(kt[s2][dt], dsb, dqacc[dt]);
+      }
     }
   }
   __syncthreads();
@@ -543,7 +586,9 @@ template <int HS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2, BUF = 2 * TILE + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
   const int BHk = p.B * p.nkv;
   int kt, bh;
   tile_order((int)blockIdx.x, (int)gridDim.x, (p.Tk + 127) / 128, BHk, p.group, kt, bh);  // low key tiles (most queries) first
@@ -553,6 +598,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int kw0 = k0 + wave * 32;
   const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
   const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
+  const float c = p.scale * kLog2e;
 
   const int key = kw0 + r;
   bfrag kf[NK], vf[NK];
@@ -561,7 +607,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     kf[ks] = zero_frag();
     vf[ks] = zero_frag();
     if (key < p.Tk) {
-      kf[ks] = *reinterpret_cast<const bfrag*>(kp + (long long)key * p.k_ts + ks * 16 + hh * 8);
+      kf[ks] = scaled_frag(kp + (long long)key * p.k_ts + ks * 16 + hh * 8, c);
       vf[ks] = *reinterpret_cast<const bfrag*>(vp + (long long)key * p.v_ts + ks * 16 + hh * 8);
     }
   }
@@ -579,75 +625,98 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       dkacc[dt][i] = 0.f;
       dvacc[dt][i] = 0.f;
     }
-  const float c = p.scale * kLog2e;
   const unsigned dthr = DROP ? drop_threshold(p.p_drop) : 0u;
   const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
 
-  Stage64<HS> qs_, ds_;
-  float stat = 0.f;  // threads 0..63: lse*log2e of query tid; threads 64..127: delta of query tid-64
-  auto issue = [&](int it) {
+  TileDma<HS> qd, dd;
+  qd.init(p.q_ts, wave, lane);
+  dd.init(p.do_ts, wave, lane);
+  const int srows = stat_rows(p.Tq);
+  const rsrc_t srs = make_rsrc(p.delta);
+  // Q and dO tiles plus the 64 + 64 row constants of iteration `it` -> buffer `buf`
+  auto issue = [&](int it, int buf) {
     const int hq = kvh * G + it / nqt, qt0 = q_start + (it % nqt) * 64;
-    const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + hq * HS;
-    const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + hq * HS;
-    qs_.issue(qp, qt0, p.Tq, p.q_ts, tid);
-    ds_.issue(dop, qt0, p.Tq, p.do_ts, tid);
-    if (tid < 128) {
-      const int qi = qt0 + (tid & 63);
-      const long long o = ((long long)b * p.nh + hq) * p.Tq + qi;
-      if (tid < 64) stat = (qi < p.Tq) ? p.lse[o] * kLog2e : INFINITY;
-      else stat = (qi < p.Tq) ? p.delta[o] : 0.f;
+    const rsrc_t qrs = make_rsrc((const bf16_t*)p.q + b * p.q_bs + hq * HS);
+    const rsrc_t drs = make_rsrc((const bf16_t*)p.dout + b * p.do_bs + hq * HS);
+    const unsigned base = lds0 + buf * BUF;
+    qd.issue(qrs, qt0, p.Tq, base);
+    dd.issue(drs, qt0, p.Tq, base + TILE);
+    if (wave < 2) {   // wave 0: -lse * log2(e), wave 1: -delta
+      const long long row = (long long)(wave == 0 ? p.B * p.nh : 0) * srows + ((long long)b * p.nh + hq) * srows + qt0;
+      dma_dwords(base + 2 * TILE + wave * 256, lane * 4, srs, __builtin_amdgcn_readfirstlane((unsigned)(row * 4)));
     }
   };
-  auto commit = [&](int buf) {
-    char* base = smem + buf * BUF;
-    qs_.commit(base, tid);
-    ds_.commit(base + TILE, tid);
-    if (tid < 128) *reinterpret_cast<float*>(base + 2 * TILE + tid * 4) = stat;
-  };
 
-  if (niter > 0) {
-    issue(0);
-    commit(0);
-  }
+  if (niter > 0) issue(0, 0);
   for (int it = 0; it < niter; ++it) {
-    if (it + 1 < niter) issue(it + 1);
+    wait_dma();
     __syncthreads();
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
     const char* qb = smem + (it & 1) * BUF;
     const char* dob = qb + TILE;
     const char* stb = qb + 2 * TILE;
     const int qt0 = q_start + (it % nqt) * 64;
     const unsigned dkey = DROP ? drop_key(p.seed, b * p.nh + kvh * G + it / nqt) : 0u;
-    auto block = [&](int sub, auto mask_tag) {
-      constexpr bool MASK = decltype(mask_tag)::value;
-      f32x16 s, dp;
+    // 32-query sub-tiles with a (query, key) pair visible to the wave: [sub_lo, sub_hi). A rolled loop:
+    // with one `if` per unrolled sub-tile the compiler copies all the dK / dV accumulators at every join.
+    const int sub_lo = qt0 + 31 + off >= kw0 ? 0 : (qt0 + 63 + off >= kw0 ? 1 : 2);
+    const int sub_hi = qt0 + 32 < p.Tq ? 2 : 1;
+#pragma unroll 1
+    for (int sub = sub_lo; sub < sub_hi; ++sub) {
+      const int qs0 = qt0 + sub * 32;
+      const char* qsub = qb + sub * (32 * HS * 2);
+      const char* dosub = dob + sub * (32 * HS * 2);
+      const char* stsub = stb + sub * 128;
+      bfrag qf[NK], dof[NK];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[i] = 0.f;
-        dp[i] = 0.f;
-      }
+      for (int ks = 0; ks < NK; ++ks) qf[ks] = row_frag<HS>(qsub, r, ks, hh);
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) s = mfma32(row_frag<HS>(qb, sub * 32 + r, ks, hh), kf[ks], s);
-#pragma unroll
-      for (int ks = 0; ks < NK; ++ks) dp = mfma32(row_frag<HS>(dob, sub * 32 + r, ks, hh), vf[ks], dp);
+      for (int ks = 0; ks < NK; ++ks) dof[ks] = row_frag<HS>(dosub, r, ks, hh);
+      f32x16 s, dp;   // start as the row constants of the 16 queries a lane's accumulators belong to
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int rr = sub * 32 + 8 * g4 + 4 * hh;
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stb + rr * 4);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stb + 256 + rr * 4);
+        const int rr = 8 * g4 + 4 * hh;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stsub + rr * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stsub + 256 + rr * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int i = 4 * g4 + j;
-          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[j]));
-          if (MASK && (key > qt0 + rr + j + off)) pv = 0.f;
-          float pd = pv, dpi = dp[i];
-          if (DROP) {
-            const bool keep = drop_keep(dkey, qt0 + rr + j, key, dthr);
-            pd = keep ? pv * rkeep : 0.f;
-            dpi = keep ? dpi * rkeep : 0.f;
-          }
-          s[i] = pd;                    // P (dropped and rescaled: the weights dV sees)
-          dp[i] = pv * (dpi - d4[j]);   // dS
+          s[4 * g4 + j] = l4[j];
+          dp[4 * g4 + j] = d4[j];
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 nd;
+      if (DROP) nd = dp;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) s = mfma32(qf[ks], kf[ks], s);
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) dp = mfma32(dof[ks], vf[ks], dp);
+      bfrag dot[2][ND], qt[2][ND];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          dot[s2][dt] = tr_frag<HS>(dosub, 0, s2, dt, lane);
+          qt[s2][dt] = tr_frag<HS>(qsub, 0, s2, dt, lane);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // compare + select only on blocks the diagonal crosses
+      if (kw0 + 31 > qs0 + off) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (key > qs0 + acc_row(i, hh) + off) s[i] = -INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(s[i]);
+        float pd = pv, dpi = dp[i];
+        if (DROP) {   // dropped pairs: P = 0 for dV, dP = 0 before delta is taken off
+          const bool keep = drop_keep(dkey, qs0 + acc_row(i, hh), key, dthr);
+          pd = keep ? pv * rkeep : 0.f;
+          dpi = keep ? (dpi - nd[i]) * rkeep + nd[i] : nd[i];
+        }
+        s[i] = pd;          // P (dropped and rescaled: the weights dV sees)
+        dp[i] = pv * dpi;   // dS
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -655,21 +724,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         const bfrag dsb = acc_frag(dp, s2);
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
-          dvacc[dt] = mfma32(tr_frag<HS>(dob, sub * 32, s2, dt, lane), pb, dvacc[dt]);
-          dkacc[dt] = mfma32(tr_frag<HS>(qb, sub * 32, s2, dt, lane), dsb, dkacc[dt]);
+          dvacc[dt] = mfma32(dot[s2][dt], pb, dvacc[dt]);
+          dkacc[dt] = mfma32(qt[s2][dt], dsb, dkacc[dt]);
         }
       }
-    };
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int qs0 = qt0 + sub * 32;
-      if (qs0 + 31 + off >= kw0 && qs0 < p.Tq) {  // wave-uniform: some (query, key) pair is visible
-        // The masked form (compare + select per score) only runs on blocks the diagonal crosses.
-        if (kw0 + 31 > qs0 + off) block(sub, std::true_type{});
-        else block(sub, std::false_type{});
-      }
     }
-    if (it + 1 < niter) commit((it + 1) & 1);
   }
   __syncthreads();
   bf16_t* dkp = (bf16_t*)p.dk + b * p.dk_bs + kvh * HS;

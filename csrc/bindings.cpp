@@ -459,7 +459,8 @@ void attn_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor
   TORCH_CHECK(lse.is_cuda() && lse.scalar_type() == at::kFloat && lse.is_contiguous() &&
                   lse.numel() == q.size(0) * q.size(1) * q.size(2),
               "attention backward: lse mismatch");
-  Tensor delta = at::empty_like(lse);
+  // row constants handed from the dQ kernel to the dK/dV kernel: [2][B * nh][Tq rounded up to 128]
+  Tensor delta = at::empty({2, q.size(0) * q.size(2), (q.size(1) + 127) / 128 * 128}, lse.options());
   p.o = o.data_ptr();
   p.o_bs = o.stride(0);
   p.o_ts = (int)o.stride(1);

@@ -63,7 +63,7 @@ struct AttnParams {
   void* o;
   float* lse;          // [B, nh, Tq] natural-log log-sum-exp of the scaled scores
   const void* dout;    // backward only
-  float* delta;        // [B, nh, Tq] rowsum(dO * O)
+  float* delta;        // backward scratch, [2][B * nh][Tq rounded up to 128]: -rowsum(dO * O), -lse * log2(e)
   void *dq, *dk, *dv;
   int B, nh, nkv, Tq, Tk, hs;
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;

@@ -12,7 +12,8 @@ from pathlib import Path
 
 import torch
 
-_LIB = Path(__file__).resolve().parent / "_C.so"
+# DPA_EXT_LIB names another build of the library (A/B timing of two builds on one machine).
+_LIB = Path(os.environ.get("DPA_EXT_LIB") or Path(__file__).resolve().parent / "_C.so")
 _loaded = False
 _error: Exception | None = None
 
