@@ -95,6 +95,9 @@ __device__ __forceinline__ void barrier() {
 
 // Exact-erf GELU and its derivative. erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
 // Phi(-|x|) = 0.5 * t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2).
+#ifndef DPA_GELU_VARIANT
+#define DPA_GELU_VARIANT 1   // 1: pairs of values through the explicitly packed form (measured 1.5 % faster on the fc shape)
+#endif
 __device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) {
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678f, 1.0f));
   const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950409f));
@@ -106,6 +109,27 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) 
   const float phi = x >= 0.f ? 1.0f - h : h;
   act = x * phi;
   dact = fmaf(x * e, 0.3989422804f, phi);
+}
+
+// The same on two values with the plain arithmetic in packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& act, f32x2& dact) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 u = pk_fma(ax, f32x2{0.3275911f * 0.70710678f, 0.3275911f * 0.70710678f}, one);
+  const f32x2 t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+  const f32x2 xx = x * x * f32x2{-0.5f * 1.4426950409f, -0.5f * 1.4426950409f};
+  const f32x2 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  f32x2 poly = pk_fma(t, f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+  poly = pk_fma(poly, t, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+  poly = pk_fma(poly, t, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+  poly = pk_fma(poly, t, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+  const f32x2 h = poly * t * e;
+  const f32x2 hm = one - h;
+  const f32x2 phi = {x[0] >= 0.f ? hm[0] : h[0], x[1] >= 0.f ? hm[1] : h[1]};
+  act = x * phi;
+  dact = pk_fma(x * e, f32x2{0.3989422804f, 0.3989422804f}, phi);
 }
 
 // vmcnt immediates of the four phases of a K-tile, and whether phases 0 and 1 issue a unit refill
@@ -543,8 +567,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
           if (EPI == kEpiGelu) {
             u32x4 g0, g1;
             float a[16], d[16];
+#if DPA_GELU_VARIANT == 1
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+              f32x2 a2, d2;
+              gelu_and_grad2(f32x2{v[j], v[j + 1]}, a2, d2);
+              a[j] = a2[0]; a[j + 1] = a2[1];
+              d[j] = d2[0]; d[j + 1] = d2[1];
+            }
+#else
 #pragma unroll
             for (int j = 0; j < 16; ++j) gelu_and_grad(v[j], a[j], d[j]);
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               o0[j] = pack_bf16x2(a[2 * j], a[2 * j + 1]);
