@@ -68,6 +68,34 @@ __global__ void ref_kernel(const bf16* a, const bf16* b, const bf16* bias, const
 
 static int g_cus = 256;
 
+#ifdef DPA_GEMM_TRACE
+namespace dpa { void gemm_nt_read_trace(unsigned long long* out); }
+// Per-phase clock stamps of two consecutive output tiles of one workgroup (waves 0 and 4 = the two wave groups).
+static void print_trace(int nk) {
+  std::vector<unsigned long long> t(8 * 128);
+  dpa::gemm_nt_read_trace(t.data());
+  for (int w : {0, 4}) {
+    const unsigned long long* s = t.data() + w * 128;
+    printf("wave %d (ticks of s_memtime; one row per K-tile: the four phase durations)\n", w);
+    for (int tile = 0; tile < 2; ++tile) {
+      const unsigned long long* b = s + 60 * tile;
+      unsigned long long prev = b[58];
+      printf(" tile %d: start-of-tile stamp %llu\n", tile, b[58] - s[58]);
+      for (int kt = 0; kt < nk; ++kt) {
+        printf("   kt %2d:", kt);
+        for (int ph = 0; ph < 4; ++ph) {
+          printf(" %5llu", b[kt * 4 + ph] - prev);
+          prev = b[kt * 4 + ph];
+        }
+        printf("\n");
+      }
+      printf("   K loop %llu, issue-ahead %llu, epilogue %llu, tile total %llu\n", b[nk * 4 - 1] - b[58], b[48] - b[nk * 4 - 1],
+             b[49] - b[48], b[49] - b[58]);
+    }
+  }
+}
+#endif
+
 struct Bufs {
   bf16 *a, *b, *c, *bias, *aux;
   long long na, nb, nc;
@@ -211,6 +239,14 @@ int main(int argc, char** argv) {
       run_case(4096, 4096, 4096, 0, false, false, 20);
     }
   }
+#ifdef DPA_GEMM_TRACE
+  if (!strcmp(mode, "trace")) {   // trace <variant> <N> <K> <epi>
+    dpa::gemm_nt_set_variant(argc > 2 ? atoi(argv[2]) : 0);
+    const int K = argc > 4 ? atoi(argv[4]) : 768;
+    run_case(65536, argc > 3 ? atoi(argv[3]) : 3072, K, argc > 5 ? atoi(argv[5]) : 0, false, false, 5);
+    print_trace(K / 64);
+  }
+#endif
   if (!strcmp(mode, "prof")) {   // prof <variant> <N> <K> <epi>: a few launches of one shape for rocprofv3
     dpa::gemm_nt_set_variant(argc > 2 ? atoi(argv[2]) : 0);
     run_case(65536, argc > 3 ? atoi(argv[3]) : 3072, argc > 4 ? atoi(argv[4]) : 768, argc > 5 ? atoi(argv[5]) : 0, false, false, 5);

@@ -46,6 +46,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 #ifndef DPA_GEMM_PREFETCH_A
 #define DPA_GEMM_PREFETCH_A 1   // phase 3 (no fragment reads of its own) reads half of the next K-tile's first A fragments
 #endif
+#ifndef DPA_GEMM_LATE_BARRIER
+#define DPA_GEMM_LATE_BARRIER 1   // the second wave group's last barrier of a tile comes after its epilogue
+#endif
 constexpr bool kPrefetchA = DPA_GEMM_PREFETCH_A != 0;
 constexpr int kStoreAux = DPA_GEMM_STORE_AUX;   // cache policy bits of the epilogue stores (1 sc0, 2 nt, 16 sc1)
 constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
@@ -140,6 +143,26 @@ struct KtCfg {
 };
 
 }  // namespace
+
+// Timing trace (benchmark builds with -DDPA_GEMM_TRACE only): every wave of one workgroup stamps the clock
+// after each phase of two consecutive output tiles into the (unused, bias-free) tail of the LDS; the
+// stamps are copied out when the workgroup ends. LDS writes only, so no vector-memory count moves.
+#ifdef DPA_GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[8 * 128];
+constexpr int kTraceWg = 37, kTraceTile = 5;
+void gemm_nt_read_trace(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 8 * 128);
+}
+#define DPA_TR(slot)                                                                                              \
+  do {                                                                                                            \
+    if (trace_base >= 0) {                                                                                        \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                 \
+      if (lane == 0) reinterpret_cast<unsigned long long*>(smem + kBiasLds)[wave * 128 + trace_base + (slot)] = t_; \
+    }                                                                                                             \
+  } while (0)
+#else
+#define DPA_TR(slot) do { } while (0)
+#endif
 
 // ABL (timing-only ablations, results wrong): 1 = no LDS-DMA in the K-loop, 2 = no fragment reads, 4 = no
 // barriers, 8 = no MFMAs.
@@ -394,7 +417,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   // One K-tile = four phases; W = vector-memory operations allowed to stay in flight at each wait
   // (8 = the four most recent units; + the epilogue's stores while they are younger than the unit
   // being waited for).
-  auto ktile = [&](int kt, int copy, auto cfg) {
+  int trace_base = -1;
+  (void)trace_base;
+  constexpr bool kLateBarrier = SYNC == 0 && DPA_GEMM_LATE_BARRIER != 0;
+  auto ktile = [&](int kt, int copy, auto cfg, bool last = false) {
     using Cfg = decltype(cfg);
     // phase 0: quadrant (rows 0-63, columns 0-31)
     read_a(copy, 0);
@@ -404,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     sync_mc();
     quadrant(0, 0, bf0);
     sync_cm();
+    DPA_TR(kt * 4 + 0);
     // phase 1: (rows 0-63, columns 32-63)
     read_b(copy, 1, bf1);
     if (Cfg::kIssue01) issue(TA{}, H1{}, kt + 1, copy ^ 1);
@@ -411,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     sync_mc();
     quadrant(0, 1, bf1);
     sync_cm();
+    DPA_TR(kt * 4 + 1);
     // phase 2: (rows 64-127, columns 32-63)
     read_a(copy, 1);
     issue(TA{}, H0{}, kt + 2, copy);
@@ -418,13 +446,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     sync_mc();
     quadrant(1, 1, bf1);
     sync_cm();
+    DPA_TR(kt * 4 + 2);
     // phase 3: (rows 64-127, columns 0-31), operands already in registers
     prefetch_a(copy ^ 1);
     issue(TB{}, H0{}, kt + 2, copy);
     wait_vm<Cfg::kW3>();
     sync_mc();
     quadrant(1, 0, bf0);
-    sync_cm();
+    // After the last K-tile the second wave group runs its epilogue BEFORE this barrier: the first group
+    // (one barrier ahead) is in its own epilogue by then, so the two epilogues overlap instead of each
+    // group waiting out the other's at the next barrier. The epilogue touches no operand LDS.
+    if (!(kLateBarrier && last && wr == 1)) sync_cm();
+    DPA_TR(kt * 4 + 3);
   };
 
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
@@ -457,6 +490,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 
   int copy = 0;
   for (int it = 0; it < ntiles; ++it) {
+#ifdef DPA_GEMM_TRACE
+    trace_base = (!BIAS && blockIdx.x == kTraceWg && nk <= 12 && (it == kTraceTile || it == kTraceTile + 1)) ? 60 * (it - kTraceTile) : -1;
+    DPA_TR(58);
+#endif
     zero_acc();
     // Waits: a unit is waited for one phase before its first read, leaving in flight the vector-memory
     // operations issued after it: 8 LDS-DMA pieces in the steady state; in the first K-tile of a tile
@@ -465,16 +502,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     // the unit in question (through phase 1 of the second K-tile).
     ktile(0, copy, KtCfg<10 + kStores, 8 + kStores, 8 + kStores, 8 + kStores, false>{});
     copy ^= 1;
-    ktile(1, copy, KtCfg<8 + kStores, 8 + kStores, 8, 8, true>{});
+    ktile(1, copy, KtCfg<8 + kStores, 8 + kStores, 8, 8, true>{}, nk == 2);
     copy ^= 1;
     for (int kt = 2; kt < nk; ++kt) {
-      ktile(kt, copy, KtCfg<8, 8, 8, 8, true>{});
+      ktile(kt, copy, KtCfg<8, 8, 8, 8, true>{}, kt == nk - 1);
       copy ^= 1;
     }
     // the two units of the next tile's second K-tile whose slots the last K-tile has finished reading:
     // issued ahead of the stores, so that nothing the next tile needs soon queues behind them
     issue(TB{}, H1{}, nk + 1, copy ^ 1);
     issue(TA{}, H1{}, nk + 1, copy ^ 1);
+    DPA_TR(48);
 
     // ---- epilogue (no barriers, no LDS-DMA: only stores, counted in the next tile's first waits) ----
     {
@@ -597,6 +635,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
           store_rows16(rsC, o0, o1, row0, colq, (unsigned)p.ldc, col_ok);
         }
     }
+    DPA_TR(49);
+    if (kLateBarrier && wr == 1) barrier();
     cur_m0 = nxt_m0;
     cur_n0 = nxt_n0;
     have_nxt = it + 2 < ntiles;
@@ -612,6 +652,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   }
   if (SYNC == 0 && wr == 0) barrier();   // pairs with the extra barrier the second wave group started with
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (zero-fill) LDS-DMA before the LDS is released
+#ifdef DPA_GEMM_TRACE
+  if (blockIdx.x == kTraceWg && !BIAS) {
+    __syncthreads();
+    for (int i = tid; i < 8 * 128; i += 512) g_gemm_trace[i] = reinterpret_cast<unsigned long long*>(smem + kBiasLds)[i];
+  }
+#endif
 }
 
 // out[C, R] = in[R, C]^T through a padded 64 x 64 LDS tile (16-byte global accesses both ways).
