@@ -53,9 +53,14 @@ constexpr bool kPrefetchA = DPA_GEMM_PREFETCH_A != 0;
 constexpr int kStoreAux = DPA_GEMM_STORE_AUX;   // cache policy bits of the epilogue stores (1 sc0, 2 nt, 16 sc1)
 constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
 constexpr int kCopy = 4 * kUnit;        // a K-tile: Am0, Am1, Bn0, Bn1
-constexpr int kBiasLds = 2 * kCopy;     // fp32 bias staged behind the two copies
+#ifndef DPA_GEMM_XPOSE
+#define DPA_GEMM_XPOSE 1   // epilogue rows regrouped through LDS: 8 consecutive lanes store (load) one 128-byte line
+#endif
+constexpr bool kXpose = DPA_GEMM_XPOSE != 0;
+constexpr int kXposeLds = 2 * kCopy;    // 2 KiB per wave: one 16-row x 64-column bf16 piece of the output tile
+constexpr int kBiasLds = kXposeLds + 8 * 2048;   // bf16 bias staged behind them
 constexpr int kMaxBiasN = kGemmNtMaxBiasN;
-constexpr int kLds = kBiasLds + kMaxBiasN * 4;   // 160 KiB
+constexpr int kLds = kBiasLds + kMaxBiasN * 2;   // 160 KiB
 
 __device__ __forceinline__ f32x4 mfma16(bfrag8 a, bfrag8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -181,9 +186,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
 
   if (BIAS) {
-    float* sb = reinterpret_cast<float*>(smem + kBiasLds);
+    bf16_t* sb = reinterpret_cast<bf16_t*>(smem + kBiasLds);
     const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
-    for (int i = tid; i < p.N; i += 512) sb[i] = bf16_to_f32(bias[i]);
+    for (int i = tid; i < p.N; i += 512) sb[i] = bias[i];
     __syncthreads();
   }
 
@@ -298,19 +303,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
 
-  // A lane holds columns colq .. colq + 15 of row row0 + l15 as two 16-byte halves. Lanes l15 and
-  // l15 ^ 8 trade one half each (DPP row rotate by 8), after which every store instruction writes 8
-  // whole 128-byte lines instead of 16 lines by half: lane l15 < 8 keeps its low half and gets the low
-  // half of row + 8, lane l15 >= 8 keeps its high half and gets the high half of row - 8.
-  auto store_rows16 = [&](__amdgpu_buffer_rsrc_t rs, u32x4 lo, u32x4 hi, int row0, int colq, unsigned ld, bool col_ok) {
+  // A lane holds columns colq .. colq + 15 of row row0 + l15 as two 16-byte halves, so neighbouring lanes hold
+  // different rows and a store instruction issued from that layout touches 64 separate lines (measured: about
+  // 72 clocks per 1 KiB store instruction, which made the epilogue cost 9 K clocks per tile). The 16-row x
+  // 64-column piece therefore goes through a wave-private 2 KiB LDS buffer (16-byte slots XOR-swizzled by
+  // the row, conflict-free both ways) and comes back with lane L holding chunk L & 7 of rows L >> 3 and
+  // (L >> 3) + 8: every 8 consecutive lanes write one whole 128-byte line. LDS operations of one wave execute
+  // in order, so the buffer needs no barrier and is reused immediately.
+  char* const tbuf = smem + kXposeLds + wave * 2048;
+  const unsigned tw0 = l15 * 128 + (((2 * q) ^ (l15 & 7)) << 4), tw1 = l15 * 128 + (((2 * q + 1) ^ (l15 & 7)) << 4);
+  const int trow = lane >> 3, tch = lane & 7;
+  const unsigned tr0 = trow * 128 + ((tch ^ (trow & 7)) << 4), tr1 = tr0 + 1024;
+  // col0 = first column of the piece in the tensor (a multiple of 64), lim = number of valid columns from col0 on
+  auto store_rows16 = [&](__amdgpu_buffer_rsrc_t rs, u32x4 lo, u32x4 hi, int row0, int col0, int lim, unsigned ld) {
+    if (kXpose) {
+      *reinterpret_cast<u32x4*>(tbuf + tw0) = lo;
+      *reinterpret_cast<u32x4*>(tbuf + tw1) = hi;
+      asm volatile("" ::: "memory");
+      const u32x4 st1 = *reinterpret_cast<const u32x4*>(tbuf + tr0), st2 = *reinterpret_cast<const u32x4*>(tbuf + tr1);
+      asm volatile("" ::: "memory");
+      const int r1 = row0 + trow, r2 = r1 + 8;
+      const bool cok = 8 * tch < lim;
+      const unsigned cb = ((unsigned)col0 + 8u * tch) * 2u;
+      const unsigned o1 = (cok && r1 < p.M) ? (unsigned)r1 * ld * 2u + cb : 0x80000000u;
+      const unsigned o2 = (cok && r2 < p.M) ? (unsigned)r2 * ld * 2u + cb : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(st1, rs, o1, 0, kStoreAux);
+      __builtin_amdgcn_raw_buffer_store_b128(st2, rs, o2, 0, kStoreAux);
+      return;
+    }
+    // register-only form: lanes l15 and l15 ^ 8 trade one half each (DPP row rotate by 8), after which a store
+    // instruction writes 8 whole lines, though still one row per lane
     const bool low = l15 < 8;
+    const bool col_ok = 16 * q < lim;
     u32x4 recv;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       recv[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(low ? hi[j] : lo[j]), 0x128, 0xf, 0xf, false);
     const u32x4 st1 = low ? lo : recv, st2 = low ? recv : hi;
     const int r1 = row0 + (l15 & 7), r2 = r1 + 8;
-    const unsigned cb = ((unsigned)colq + (low ? 0u : 8u)) * 2u;
+    const unsigned cb = ((unsigned)col0 + 16u * q + (low ? 0u : 8u)) * 2u;
     const unsigned o1 = (col_ok && r1 < p.M) ? (unsigned)r1 * ld * 2u + cb : 0x80000000u;
     const unsigned o2 = (col_ok && r2 < p.M) ? (unsigned)r2 * ld * 2u + cb : 0x80000000u;
     __builtin_amdgcn_raw_buffer_store_b128(st1, rs, o1, 0, kStoreAux);
@@ -462,6 +493,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(p.aux_out, 0, (int)p.aux_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux_in), 0, (int)p.aux_bytes, 0x00020000);
   // epilogue stores per wave and tile
   constexpr int kStores = (EPI == kEpiGelu || EPI == kEpiDswiglu) ? 32 : (EPI == kEpiSwiglu ? 24 : 16);
 
@@ -519,11 +552,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       // first of this lane's 16 columns (paired tiles: of its 8 output columns)
       const int colq = kPair ? (cur_n0 >> 1) + 32 * wc + 8 * q : cur_n0 + 64 * wc + 16 * q;
       const bool col_ok = colq < p.N;
+      const int col0 = cur_n0 + 64 * wc, lim = p.N - col0;   // the wave's 64 columns (unpaired tiles)
+      // bias of the lane's 16 columns: as floats, or (forms that also hold the auxiliary pieces in registers)
+      // packed as loaded and unpacked at each use
+      constexpr bool kBiasPacked = BIAS && kXpose && (EPI == kEpiMul || EPI == kEpiAdd);
       float bv[16];
+      u32x4 bp0 = {0u, 0u, 0u, 0u}, bp1 = {0u, 0u, 0u, 0u};
       if (BIAS) {
-        const float* sb = reinterpret_cast<const float*>(smem + kBiasLds);
+        // N is a multiple of 16 and colq of 16: the 32 bytes are inside the staged row or skipped
+        const u32x4* sb = reinterpret_cast<const u32x4*>(smem + kBiasLds + (col_ok ? colq * 2 : 0));
+        if (col_ok) {
+          bp0 = sb[0];
+          bp1 = sb[1];
+        }
+        if (!kBiasPacked) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bv[j] = col_ok ? sb[colq + j] : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            bv[2 * j] = lo_bf16(bp0[j]);
+            bv[2 * j + 1] = hi_bf16(bp0[j]);
+            bv[8 + 2 * j] = lo_bf16(bp1[j]);
+            bv[8 + 2 * j + 1] = hi_bf16(bp1[j]);
+          }
+        }
+      }
+      auto bias_at = [&](int c) -> float {
+        if (!BIAS) return 0.f;
+        if (!kBiasPacked) return bv[c];
+        const unsigned w = c < 8 ? bp0[c >> 1] : bp1[(c - 8) >> 1];
+        return (c & 1) ? hi_bf16(w) : lo_bf16(w);
+      };
+      // The auxiliary operand (multiply / add forms) is read the way the output is written: lane L fetches
+      // chunk L & 7 of rows L >> 3 and (L >> 3) + 8 of each 16-row piece (8 lanes per 128-byte line), all
+      // pieces ahead of the first store so that no load queues behind a store; the pieces are turned into the
+      // accumulator layout through the transposition buffer. Rows / columns past the end read as zeros.
+      constexpr bool kAuxX = kXpose && (EPI == kEpiMul || EPI == kEpiAdd);
+      u32x4 ax[2][4][2];
+      if (kAuxX) {
+        const bool cok = 8 * tch < lim;
+        const unsigned cb = ((unsigned)col0 + 8u * tch) * 2u;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int r1 = cur_m0 + 128 * wr + 64 * mh + 16 * mt + trow, r2 = r1 + 8;
+            const unsigned o1 = (cok && r1 < p.M) ? (unsigned)r1 * (unsigned)p.ld_aux * 2u + cb : 0x80000000u;
+            const unsigned o2 = (cok && r2 < p.M) ? (unsigned)r2 * (unsigned)p.ld_aux * 2u + cb : 0x80000000u;
+            ax[mh][mt][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o1, 0, 0);
+            ax[mh][mt][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o2, 0, 0);
+          }
       }
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
@@ -536,11 +612,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
           for (int T = 0; T < 4; ++T)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * T + e] = acc[mh][mt][T][e] + (BIAS ? bv[4 * T + e] : 0.f);
+            for (int e = 0; e < 4; ++e) v[4 * T + e] = acc[mh][mt][T][e] + bias_at(4 * T + e);
           if (EPI == kEpiMul || EPI == kEpiAdd) {
-            const unsigned xoff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0u;
-            const u32x4* xp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux_in) + xoff);
-            const u32x4 x0 = xp[0], x1 = xp[1];
+            u32x4 x0, x1;
+            if (kAuxX) {
+              *reinterpret_cast<u32x4*>(tbuf + tr0) = ax[mh][mt][0];
+              *reinterpret_cast<u32x4*>(tbuf + tr1) = ax[mh][mt][1];
+              asm volatile("" ::: "memory");
+              x0 = *reinterpret_cast<const u32x4*>(tbuf + tw0);
+              x1 = *reinterpret_cast<const u32x4*>(tbuf + tw1);
+              asm volatile("" ::: "memory");
+            } else {
+              const unsigned xoff = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0u;
+              const u32x4* xp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux_in) + xoff);
+              x0 = xp[0];
+              x1 = xp[1];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float a0 = lo_bf16(x0[j]), a1 = hi_bf16(x0[j]), a2 = lo_bf16(x1[j]), a3 = hi_bf16(x1[j]);
@@ -597,8 +684,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
               du0[j] = pack_bf16x2(duv[0], duv[1]);
               du1[j] = pack_bf16x2(duv[2], duv[3]);
             }
-            store_rows16(rsC, dg0, dg1, row0, colq, (unsigned)p.ldc, col_ok);
-            store_rows16(rsC, du0, du1, row0, colq + p.N, (unsigned)p.ldc, col_ok);
+            store_rows16(rsC, dg0, dg1, row0, col0, lim, (unsigned)p.ldc);
+            store_rows16(rsC, du0, du1, row0, col0 + p.N, lim, (unsigned)p.ldc);
             continue;
           }
           u32x4 o0, o1;
@@ -624,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
               g0[j] = pack_bf16x2(d[2 * j], d[2 * j + 1]);
               g1[j] = pack_bf16x2(d[8 + 2 * j], d[8 + 2 * j + 1]);
             }
-            store_rows16(rsG, g0, g1, row0, colq, (unsigned)p.ld_aux, col_ok);
+            store_rows16(rsG, g0, g1, row0, col0, lim, (unsigned)p.ld_aux);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -632,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
               o1[j] = pack_bf16x2(v[8 + 2 * j], v[8 + 2 * j + 1]);
             }
           }
-          store_rows16(rsC, o0, o1, row0, colq, (unsigned)p.ldc, col_ok);
+          store_rows16(rsC, o0, o1, row0, col0, lim, (unsigned)p.ldc);
         }
     }
     DPA_TR(49);

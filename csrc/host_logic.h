@@ -11,7 +11,7 @@
 
 namespace dpa {
 
-constexpr int kGemmNtMaxBiasN = 8192;   // fp32 bias row kept in LDS: 32 KiB
+constexpr int kGemmNtMaxBiasN = 8192;   // bf16 bias row kept in LDS: 16 KiB
 
 struct TileCoord {
   int m0, n0;
