@@ -155,7 +155,9 @@ class GQA(nn.Module):
         self.attn_dropout = nn.Dropout(config.dropout)   # kept for module-tree parity; unused like the reference's
         self.resid_dropout = nn.Dropout(config.dropout)
 
-    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False):
+    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False, residual=None):
+        """``residual`` (the block's residual stream) is added to the output projection inside its GEMM;
+        the result is then the updated stream, not the attention branch alone."""
         B, T, C = x.shape
         nh, nkv, hs = self.config.n_head, self.config.n_kv_heads, self.head_size
         p_drop = self.config.dropout if self.training else 0.0
@@ -182,8 +184,10 @@ class GQA(nn.Module):
             y = ops.causal_attention(q, k, v, dropout_p=p_drop)
             new_cache = (k.transpose(1, 2), v.transpose(1, 2))  # reference cache shape (B, nkv, T, hs)
         y = y.reshape(B, T, C)
+        if residual is not None and not (self.training and self.config.dropout > 0.0):
+            return ops.linear(y, self.c_proj.weight, self.c_proj.bias, sole_use=True, residual=residual), new_cache
         y = _drop(ops.linear(y, self.c_proj.weight, self.c_proj.bias, sole_use=True), self.config.dropout, self.training)
-        return y, new_cache
+        return (y if residual is None else residual + y), new_cache
 
     def _want_cache(self) -> bool:
         # The training / validation path never reads the returned cache; building it would only
@@ -342,10 +346,12 @@ class Attention(nn.Module):
         else:
             raise ValueError(f"unknown attention {config.attn!r}")
 
-    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False):
+    def forward(self, x, rope=None, kv_cache=None, VAL_RUN=False, residual=None):
         if isinstance(self.attn, GQA):
             self.attn._val_run = VAL_RUN
-        return self.attn(x, rope, kv_cache, VAL_RUN)
+            return self.attn(x, rope, kv_cache, VAL_RUN, residual)
+        y, new_cache = self.attn(x, rope, kv_cache, VAL_RUN)
+        return (y if residual is None else residual + y), new_cache
 
 
 # ---------------------------------------------------------------------------------------------
@@ -364,16 +370,22 @@ class MLP(nn.Module):
         self.dropout = nn.Dropout(config.dropout)
         self.p_drop = config.dropout
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (the block's residual stream) is added to the second product inside its GEMM; the
+        result is then the updated stream, not the feed-forward branch alone."""
+        if residual is not None and self.training and self.p_drop > 0.0:
+            return residual + self.forward(x)   # dropout sits between the product and the add
         if self.non_linearity == "gelu" and ops.mlp_gelu_supported(x, self.c_fc.weight, self.c_proj.weight):
             # both products on the own GEMM, GELU / GELU' in its epilogues
-            return _drop(ops.mlp_gelu(x, self.c_fc.weight, self.c_proj.weight, sole_use=True), self.p_drop, self.training)
+            return _drop(ops.mlp_gelu(x, self.c_fc.weight, self.c_proj.weight, sole_use=True, residual=residual),
+                         self.p_drop, self.training)
         if self.non_linearity == "swiglu" and ops.mlp_swiglu_supported(x, self.c_fc.weight, self.c_proj.weight):
             # gate and up columns paired inside the c_fc GEMM's tiles, SwiGLU and its gradient in the epilogues
-            return _drop(ops.mlp_swiglu(x, self.c_fc.weight, self.c_proj.weight, sole_use=True), self.p_drop, self.training)
+            return _drop(ops.mlp_swiglu(x, self.c_fc.weight, self.c_proj.weight, sole_use=True, residual=residual),
+                         self.p_drop, self.training)
         h = ops.linear(x, self.c_fc.weight, sole_use=True)
         h = ops.swiglu(h) if self.non_linearity == "swiglu" else self._act(h)
-        return _drop(ops.linear(h, self.c_proj.weight, sole_use=True), self.p_drop, self.training)
+        return _drop(ops.linear(h, self.c_proj.weight, sole_use=True, residual=residual), self.p_drop, self.training)
 
 
 class Expert(nn.Module):
@@ -504,6 +516,9 @@ class Block(nn.Module):
         # attention-only recomputation lives here; whole-block recomputation in LLM.forward
         self.act_recomp = config.act_recomp and getattr(config, "act_recomp_scope", "attn") == "attn"
         self.attn = Attention(config)
+        self.gqa = config.attn in ("mha", "mqa", "gqa")
+        # off while dropout is active in training (it sits between the branch and the add)
+        self.fuse_residual = not config.dropout > 0.0
         self.ln1 = nn.LayerNorm(config.n_embd)
         self.ln2 = nn.LayerNorm(config.n_embd)
         if config.moe:
@@ -512,18 +527,39 @@ class Block(nn.Module):
             self.mlp = MLP(config)
 
     def forward(self, x, delta=None, rope=None, kv_cache=None, VAL_RUN=False):
-        if delta is None:
-            h = ops.layer_norm(x, self.ln1.weight, self.ln1.bias, self.ln1.eps)
-        else:
+        # Residual adds ride in the epilogue of the GEMM that produces the branch (GQA output projection,
+        # second feed-forward product) where that GEMM exists and no dropout sits in between: the LayerNorm
+        # kernels then read the stream once instead of reading stream + branch and writing the sum back.
+        # Elsewhere (latent attention, experts, active dropout) the add stays inside the next LayerNorm kernel.
+        # (GPU and at least the GEMM kernel's minimum of rows: decode steps keep the LayerNorm form)
+        mode = os.environ.get("DPA_FUSE_RESIDUAL", "1")
+        on = self.fuse_residual and mode != "0" and (mode == "force" or (x.is_cuda and x.shape[0] * x.shape[1] >= 512))
+        fuse_attn = on and self.gqa
+        fuse_mlp = on and not self.is_moe
+        if delta is not None:
             x, h = ops.add_layer_norm(x, delta, self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        elif fuse_attn:
+            x, h = ops.layer_norm_keep(x, self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        else:
+            h = ops.layer_norm(x, self.ln1.weight, self.ln1.bias, self.ln1.eps)
+        res = x if fuse_attn else None
         if self.act_recomp and self.training and kv_cache is None:
-            attn_out, new_cache = checkpoint(self.attn, h, rope, kv_cache, VAL_RUN, use_reentrant=False,
+            attn_out, new_cache = checkpoint(self.attn, h, rope, kv_cache, VAL_RUN, res, use_reentrant=False,
                                              context_fn=_ckpt_contexts)
         else:
-            attn_out, new_cache = self.attn(h, rope, kv_cache, VAL_RUN)
-        x, h2 = ops.add_layer_norm(x, attn_out, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+            attn_out, new_cache = self.attn(h, rope, kv_cache, VAL_RUN, res)
+        if fuse_attn:
+            x = attn_out   # the updated stream
+            if fuse_mlp:
+                x, h2 = ops.layer_norm_keep(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+            else:
+                h2 = ops.layer_norm(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+        else:
+            x, h2 = ops.add_layer_norm(x, attn_out, self.ln2.weight, self.ln2.bias, self.ln2.eps)
         if self.is_moe:
             out, aux_loss = self.moe(h2)
+        elif fuse_mlp:
+            return self.mlp(h2, x), None, new_cache, 0.0
         else:
             out, aux_loss = self.mlp(h2), 0.0
         return x, out, new_cache, aux_loss

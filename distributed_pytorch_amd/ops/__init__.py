@@ -13,7 +13,7 @@ from .moe import (expert_counts, gather_combine, grouped_experts, grouped_expert
                   grouped_supported,
                   plan_dense, scatter_rows, topk_gate)
 from .moe import plan as moe_plan
-from .norm import add_layer_norm, layer_norm
+from .norm import add_layer_norm, layer_norm, layer_norm_keep
 from .optim import adamw_step, sumsq
 from .rope import apply_rope, rope_inplace_, rope_tables, rope_qkv_
 from .sampling import sample_eager, sample_fused
@@ -21,7 +21,7 @@ from .sampling import sample_eager, sample_fused
 __all__ = [
     "gelu", "swiglu", "get_activation", "cached_attention", "causal_attention", "causal_attention_eager", "causal_self_attention_qkv", "dropout_keep_mask", "kv_append",
     "rope_qkv_", "split_qkv", "embedding", "cross_entropy", "linear_cross_entropy", "vocab_parallel_cross_entropy", "vocab_parallel_linear_cross_entropy",
-    "IGNORE_INDEX", "layer_norm", "add_layer_norm", "adamw_step", "sumsq", "apply_rope", "rope_inplace_",
+    "IGNORE_INDEX", "layer_norm", "add_layer_norm", "layer_norm_keep", "adamw_step", "sumsq", "apply_rope", "rope_inplace_",
     "rope_tables", "linear", "mlp_gelu", "mlp_gelu_supported", "mlp_swiglu", "mlp_swiglu_supported", "bump_weights_epoch", "transposed_weight", "weight_grad", "wgrad_supported", "grouped_experts", "grouped_experts_eager",
     "grouped_supported", "expert_counts", "sample_eager", "sample_fused", "topk_gate", "moe_plan", "plan_dense", "scatter_rows", "gather_combine",
 ]

@@ -194,14 +194,31 @@ def _param_grads(w_param, b_param, dy2, x2, need_w: bool, need_b: bool):
     return dw, db
 
 
+def _residual_rows(residual, w):
+    """The residual as [rows, N] rows the add epilogue can read, or None."""
+    if residual is None or residual.dtype != torch.bfloat16 or residual.shape[-1] != w.shape[0]:
+        return None
+    r2 = residual.reshape(-1, residual.shape[-1])
+    return r2 if (r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0) else None
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, sole_use):
+    def forward(ctx, x, w, b, sole_use, residual=None):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.w_param = w if sole_use else None
         ctx.b_param = b if sole_use else None
         x2 = x.reshape(-1, x.shape[-1])
+        if residual is not None:
+            # y = x W^T + b + residual: the add is the GEMM's epilogue where the kernel takes the shape
+            r2 = _residual_rows(residual, w)
+            if r2 is not None and r2.shape[0] == x2.shape[0] and gemm_supported(x2, w, b, r2):
+                y = ops().gemm_nt(x2, w, b, _EPI_ADD, r2)[0]
+                return torch.ops.aten._unsafe_view(y, (*x.shape[:-1], w.shape[0]))
+            y = ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0].view(*x.shape[:-1], w.shape[0]) if gemm_supported(x2, w, b) \
+                else F.linear(x, w, b)
+            return y + residual
         if gemm_supported(x2, w, b):
             # _unsafe_view: the freshly made GEMM output reshaped WITHOUT view tracking, so that the caller
             # may update it in place (rotary embedding of the q / k columns) like any tensor it owns
@@ -218,7 +235,18 @@ class _LinearFn(torch.autograd.Function):
             dx = _input_grad(dy2, w).view(x.shape)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = _param_grads(ctx.w_param, ctx.b_param, dy2, x2, ctx.needs_input_grad[1], need_b)
-        return dx, dw, db, None
+        # the residual's gradient is dy itself
+        return dx, dw, db, None, (dy if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None)
+
+
+def _second_product(act, w_proj, residual):
+    """c_proj of the fused feed-forward blocks: act W_proj^T (+ residual in the GEMM's epilogue)."""
+    if residual is not None:
+        r2 = _residual_rows(residual, w_proj)
+        if r2 is not None and r2.shape[0] == act.shape[0] and ops().gemm_nt_supported(act, w_proj, None, r2):
+            return ops().gemm_nt(act, w_proj, None, _EPI_ADD, r2)[0]
+        return ops().gemm_nt(act, w_proj, None, _EPI_NONE, None)[0] + residual.reshape(act.shape[0], -1)
+    return ops().gemm_nt(act, w_proj, None, _EPI_NONE, None)[0]
 
 
 class _MlpGeluFn(torch.autograd.Function):
@@ -228,14 +256,14 @@ class _MlpGeluFn(torch.autograd.Function):
     input gradient of c_proj comes out of its GEMM already multiplied by gelu'(h)."""
 
     @staticmethod
-    def forward(ctx, x, w_fc, w_proj, sole_use):
+    def forward(ctx, x, w_fc, w_proj, sole_use, residual=None):
         x2 = x.reshape(-1, x.shape[-1])
         act, dact = ops().gemm_nt(x2, w_fc, None, _EPI_GELU, None)
-        y = ops().gemm_nt(act, w_proj, None, _EPI_NONE, None)[0]
+        y = _second_product(act, w_proj, residual)
         ctx.save_for_backward(x, w_fc, w_proj, act, dact)
         ctx.fc_param = w_fc if sole_use else None
         ctx.proj_param = w_proj if sole_use else None
-        return y.view(*x.shape[:-1], w_proj.shape[0])
+        return torch.ops.aten._unsafe_view(y, (*x.shape[:-1], w_proj.shape[0]))
 
     @staticmethod
     def backward(ctx, dy):
@@ -249,7 +277,7 @@ class _MlpGeluFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dh, w_fc).view(x.shape)
         dw_fc, _ = _param_grads(ctx.fc_param, None, dh, x2, ctx.needs_input_grad[1], False)
-        return dx, dw_fc, dw_proj, None
+        return dx, dw_fc, dw_proj, None, (dy if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None)
 
 
 class _MlpSwigluFn(torch.autograd.Function):
@@ -259,10 +287,10 @@ class _MlpSwigluFn(torch.autograd.Function):
     the input gradient of c_proj leaves its GEMM already turned into ``[dgate | dup]``."""
 
     @staticmethod
-    def forward(ctx, x, w_fc, w_proj, sole_use):
+    def forward(ctx, x, w_fc, w_proj, sole_use, residual=None):
         x2 = x.reshape(-1, x.shape[-1])
         act, h = ops().gemm_nt(x2, w_fc, None, _EPI_SWIGLU, None)
-        y = ops().gemm_nt(act, w_proj, None, _EPI_NONE, None)[0]
+        y = _second_product(act, w_proj, residual)
         ctx.save_for_backward(x, w_fc, w_proj, act, h)
         ctx.fc_param = w_fc if sole_use else None
         ctx.proj_param = w_proj if sole_use else None
@@ -279,7 +307,7 @@ class _MlpSwigluFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dh, w_fc).view(x.shape)
         dw_fc, _ = _param_grads(ctx.fc_param, None, dh, x2, ctx.needs_input_grad[1], False)
-        return dx, dw_fc, dw_proj, None
+        return dx, dw_fc, dw_proj, None, (dy if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None)
 
 
 def mlp_swiglu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor) -> bool:
@@ -298,9 +326,11 @@ def mlp_swiglu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tens
     return bool(ops().gemm_nt_pair_supported(x2, w_fc, _EPI_SWIGLU, None))
 
 
-def mlp_swiglu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False) -> torch.Tensor:
-    """Fused SwiGLU feed-forward block; callers check ``mlp_swiglu_supported`` first."""
-    return _MlpSwigluFn.apply(x, w_fc, w_proj, sole_use)
+def mlp_swiglu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False,
+               residual: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused SwiGLU feed-forward block (``+ residual`` in the second GEMM's epilogue); callers check
+    ``mlp_swiglu_supported`` first."""
+    return _MlpSwigluFn.apply(x, w_fc, w_proj, sole_use, residual)
 
 
 def mlp_gelu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor) -> bool:
@@ -316,19 +346,28 @@ def mlp_gelu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor
             and tuple(w_proj.shape) == (C, up) and x2.shape[0] * max(up, C) * 2 < 2 ** 31)
 
 
-def mlp_gelu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False) -> torch.Tensor:
-    """Fused feed-forward block with exact-erf GELU; callers check ``mlp_gelu_supported`` first."""
-    return _MlpGeluFn.apply(x, w_fc, w_proj, sole_use)
+def mlp_gelu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False,
+             residual: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused feed-forward block with exact-erf GELU (``+ residual`` in the second GEMM's epilogue); callers
+    check ``mlp_gelu_supported`` first."""
+    return _MlpGeluFn.apply(x, w_fc, w_proj, sole_use, residual)
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, sole_use: bool = False) -> torch.Tensor:
-    """``x @ w.T + b``. ``sole_use=True`` promises that this call is the only consumer of ``w`` in
-    the forward pass, which allows its gradient to be accumulated straight into the owning
-    engine's flat gradient buffer (see ``_direct_target``)."""
+def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, sole_use: bool = False,
+           residual: torch.Tensor | None = None) -> torch.Tensor:
+    """``x @ w.T + b (+ residual)``. ``sole_use=True`` promises that this call is the only consumer of
+    ``w`` in the forward pass, which allows its gradient to be accumulated straight into the owning
+    engine's flat gradient buffer (see ``_direct_target``). ``residual`` (same shape as the result) is
+    added in the GEMM's epilogue on the GPU."""
     if use_hip(x, w) and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
-        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-            return _LinearFn.apply(x, w, b, sole_use)
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (residual is not None and residual.requires_grad)):
+            return _LinearFn.apply(x, w, b, sole_use, residual)
         x2 = x.reshape(-1, x.shape[-1])
-        if gemm_supported(x2, w, b):
+        if residual is not None:
+            r2 = _residual_rows(residual, w)
+            if r2 is not None and r2.shape[0] == x2.shape[0] and gemm_supported(x2, w, b, r2):
+                return ops().gemm_nt(x2, w, b, _EPI_ADD, r2)[0].view(*x.shape[:-1], w.shape[0])
+        elif gemm_supported(x2, w, b):
             return ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0].view(*x.shape[:-1], w.shape[0])
-    return F.linear(x, w, b)
+    y = F.linear(x, w, b)
+    return y if residual is None else y + residual

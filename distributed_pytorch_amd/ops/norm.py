@@ -2,6 +2,7 @@
 
 ``layer_norm(x, w, b)``                -> y
 ``add_layer_norm(x, r, w, b)``         -> (x + r, LN(x + r))   one pass over memory
+``layer_norm_keep(x, w, b)``           -> (x, LN(x))           x's other consumers send their gradient here
 
 Reference behaviour: ``nn.LayerNorm(C)`` with eps 1e-5, affine weight and bias
 (reference: single-gpu/model.py:514-515,557).
@@ -36,7 +37,7 @@ def _direct_targets(w, b):
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, w, b, eps):
+    def forward(ctx, x, res, w, b, eps, keep=False):
         ctx.params = (w, b)
         xc = x.contiguous()
         rc = res.contiguous() if res is not None else None
@@ -44,8 +45,13 @@ class _LayerNormFn(torch.autograd.Function):
         ln_in = s if res is not None else xc
         ctx.save_for_backward(ln_in, w, mean, rstd)
         ctx.has_res = res is not None
+        ctx.keep = keep
         if res is not None:
             return s, y
+        if keep:
+            # the input handed back as a second output: whatever else consumes it downstream sends its
+            # gradient through this node, where it is added inside the backward kernel
+            return x, y
         return y
 
     @staticmethod
@@ -54,13 +60,20 @@ class _LayerNormFn(torch.autograd.Function):
         if ctx.has_res:
             ds, dy = grads
             if dy is None:
-                return ds, ds, None, None, None
+                return ds, ds, None, None, None, None
             dres = ds.contiguous() if ds is not None else None
             dx, dw, db = _ln_backward(ctx, dy.contiguous(), ln_in, w, mean, rstd, dres)
-            return dx, dx, dw, db, None
+            return dx, dx, dw, db, None, None
+        if ctx.keep:
+            ds, dy = grads
+            if dy is None:
+                return ds, None, None, None, None, None
+            dres = ds.contiguous() if ds is not None else None
+            dx, dw, db = _ln_backward(ctx, dy.contiguous(), ln_in, w, mean, rstd, dres)
+            return dx, None, dw, db, None, None
         (dy,) = grads
         dx, dw, db = _ln_backward(ctx, dy.contiguous(), ln_in, w, mean, rstd, None)
-        return dx, None, dw, db, None
+        return dx, None, dw, db, None, None
 
 
 def _ln_backward(ctx, dy, ln_in, w, mean, rstd, dres):
@@ -77,6 +90,15 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1
     if _hip_ok(x, w):
         return _LayerNormFn.apply(x, None, w, b, eps)
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def layer_norm_keep(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    """Returns ``(x, layer_norm(x))``. Use the returned ``x`` for every further consumer of the input (a
+    residual connection): its gradient then arrives at this node and is added to the LayerNorm's input
+    gradient inside the backward kernel instead of by a separate accumulation pass."""
+    if _hip_ok(x, w):
+        return _LayerNormFn.apply(x, None, w, b, eps, True)
+    return x, F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
 def add_layer_norm(x: torch.Tensor, r: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):

@@ -57,10 +57,11 @@ def emulate_direct(monkeypatch):
         return w_param.grad if getattr(w_param, "_dpa_direct", False) and w_param.grad is not None else None
     monkeypatch.setattr(lin, "_direct_target", direct_target)
 
-    def linear(x, w, b=None, sole_use=False):
+    def linear(x, w, b=None, sole_use=False, residual=None):
         if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-            return lin._LinearFn.apply(x, w, b, sole_use)
-        return F.linear(x, w, b)
+            return lin._LinearFn.apply(x, w, b, sole_use, residual)
+        y = F.linear(x, w, b)
+        return y if residual is None else y + residual
     monkeypatch.setattr(lin, "linear", linear)
     import distributed_pytorch_amd.ops as ops_pkg
     monkeypatch.setattr(ops_pkg, "linear", linear)
