@@ -47,9 +47,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)   # after >= 10 warm-up steps
     ap.add_argument("--mode", type=str, default="ddp", choices=["single", "ddp", "zero1", "zero2", "fsdp", "fsdp_keep", "ep", "ep_fsdp"])
     ap.add_argument("--model", type=str, default="gpt2-124m", choices=sorted(PRESETS))
-    # 128 sequences per GPU: +3 % tokens/s over 64 (fewer tile tails per kernel; 256 adds another 1.3 %),
-    # 41 GB of the 288 GB, and twice the backward time for the gradient collectives to hide under
-    ap.add_argument("--batch", type=int, default=128, help="micro-batch (sequences) per GPU")
+    # 256 sequences per GPU: +3 % tokens/s over 64 at 128 and another 1.9 % at 256 (fewer tile tails per
+    # kernel, the optimizer pass and the gradient folds spread over more tokens), 85 GB of the 288 GB, and
+    # four times the backward time for the gradient collectives to hide under. 256 is also the most the
+    # 32-bit buffer offsets of the GEMM kernels take at width 3072.
+    ap.add_argument("--batch", type=int, default=256, help="micro-batch (sequences) per GPU")
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--bucket_mb", type=float, default=48.0)
