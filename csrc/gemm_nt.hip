@@ -49,7 +49,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 #ifndef DPA_GEMM_LATE_BARRIER
 #define DPA_GEMM_LATE_BARRIER 1   // the second wave group's last barrier of a tile comes after its epilogue
 #endif
-constexpr bool kPrefetchA = DPA_GEMM_PREFETCH_A != 0;
+#ifndef DPA_GEMM_PHASES
+#define DPA_GEMM_PHASES 2   // phases (memory section + compute section) per K-tile: 2 x 32 MFMAs or 4 x 16
+#endif
+constexpr bool kTwoPhase = DPA_GEMM_PHASES == 2;
+constexpr bool kPrefetchA = DPA_GEMM_PREFETCH_A != 0 && !kTwoPhase;   // (the 2-phase order leaves no landed unit to read early)
 constexpr int kStoreAux = DPA_GEMM_STORE_AUX;   // cache policy bits of the epilogue stores (1 sc0, 2 nt, 16 sc1)
 constexpr int kUnit = 16384;            // one LDS unit: 128 rows x 64 k x 2 bytes
 constexpr int kCopy = 4 * kUnit;        // a K-tile: Am0, Am1, Bn0, Bn1
@@ -451,7 +455,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   int trace_base = -1;
   (void)trace_base;
   constexpr bool kLateBarrier = SYNC == 0 && DPA_GEMM_LATE_BARRIER != 0;
-  auto ktile = [&](int kt, int copy, auto cfg, bool last = false) {
+  // Two phases per K-tile: A = rows 0-63 x 64 columns (16 fragment reads, 32 MFMAs), B = rows 64-127 (8 reads,
+  // 32 MFMAs). Each section boundary costs a latency tail in which neither the LDS pipe nor the matrix pipe
+  // works, so half as many sections per K-tile are faster although the LDS traffic is the same. Refill order
+  // of the stream: Am0, Bn0, Bn1 of K-tile kt + 2 in phase B of kt (their slots were read in phase A), Am1 of
+  // kt + 1 in phase A of kt (read in phase B of kt - 1); every unit is waited for one phase before its first
+  // read, a K-tile after its issue, with the 8 youngest pieces (4 units) left in flight.
+  auto ktile2 = [&](int kt, int copy, auto cfg, bool last = false) {
+    using Cfg = decltype(cfg);
+    read_a(copy, 0);
+    read_b(copy, 0, bf0);
+    read_b(copy, 1, bf1);
+    if (Cfg::kIssue01) issue(TA{}, H1{}, kt + 1, copy ^ 1);
+    wait_vm<Cfg::kW0>();
+    sync_mc();
+    DPA_TR(kt * 4 + 0);
+    quadrant(0, 0, bf0);
+    quadrant(0, 1, bf1);
+    sync_cm();
+    DPA_TR(kt * 4 + 1);
+    read_a(copy, 1);
+    issue(TA{}, H0{}, kt + 2, copy);
+    issue(TB{}, H0{}, kt + 2, copy);
+    issue(TB{}, H1{}, kt + 2, copy);
+    wait_vm<Cfg::kW2>();
+    sync_mc();
+    DPA_TR(kt * 4 + 2);
+    quadrant(1, 1, bf1);
+    quadrant(1, 0, bf0);
+    if (!(kLateBarrier && last && wr == 1)) sync_cm();   // see ktile4
+    DPA_TR(kt * 4 + 3);
+  };
+  auto ktile4 = [&](int kt, int copy, auto cfg, bool last = false) {
     using Cfg = decltype(cfg);
     // phase 0: quadrant (rows 0-63, columns 0-31)
     read_a(copy, 0);
@@ -515,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     for (int i = 0; i < kStores; ++i)   // distinct offsets: identical stores would be merged into one
       __builtin_amdgcn_raw_buffer_store_b128(z, rsC, 0x80000000u + 16u * i, 0, 0);
   }
-  wait_vm<12 + kStores>();
+  wait_vm<(kTwoPhase ? 10 : 12) + kStores>();   // the units the first memory section reads
   barrier();
   if (SYNC == 0 && wr == 1) barrier();   // the second wave group runs one barrier behind the first
   prefetch_a(0);
@@ -533,18 +568,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     // two more (its phases 0 and 1 issue nothing: both copies were filled ahead, the last two units
     // at the start of the previous epilogue), plus that epilogue's stores while they are younger than
     // the unit in question (through phase 1 of the second K-tile).
-    ktile(0, copy, KtCfg<10 + kStores, 8 + kStores, 8 + kStores, 8 + kStores, false>{});
-    copy ^= 1;
-    ktile(1, copy, KtCfg<8 + kStores, 8 + kStores, 8, 8, true>{}, nk == 2);
-    copy ^= 1;
-    for (int kt = 2; kt < nk; ++kt) {
-      ktile(kt, copy, KtCfg<8, 8, 8, 8, true>{}, kt == nk - 1);
+    if (kTwoPhase) {
+      // 2-phase waits: phase A of the first K-tile issues nothing (its unit went out ahead of the previous
+      // epilogue); the previous epilogue's stores are younger than the awaited unit through phase A of the
+      // second K-tile.
+      ktile2(0, copy, KtCfg<8 + kStores, 0, 8 + kStores, 0, false>{});
       copy ^= 1;
+      ktile2(1, copy, KtCfg<8 + kStores, 0, 8, 0, true>{}, nk == 2);
+      copy ^= 1;
+      for (int kt = 2; kt < nk; ++kt) {
+        ktile2(kt, copy, KtCfg<8, 0, 8, 0, true>{}, kt == nk - 1);
+        copy ^= 1;
+      }
+      issue(TA{}, H1{}, nk + 1, copy ^ 1);   // ahead of the stores: the slot's last reader was the last phase B
+    } else {
+      ktile4(0, copy, KtCfg<10 + kStores, 8 + kStores, 8 + kStores, 8 + kStores, false>{});
+      copy ^= 1;
+      ktile4(1, copy, KtCfg<8 + kStores, 8 + kStores, 8, 8, true>{}, nk == 2);
+      copy ^= 1;
+      for (int kt = 2; kt < nk; ++kt) {
+        ktile4(kt, copy, KtCfg<8, 8, 8, 8, true>{}, kt == nk - 1);
+        copy ^= 1;
+      }
+      // the two units of the next tile's second K-tile whose slots the last K-tile has finished reading:
+      // issued ahead of the stores, so that nothing the next tile needs soon queues behind them
+      issue(TB{}, H1{}, nk + 1, copy ^ 1);
+      issue(TA{}, H1{}, nk + 1, copy ^ 1);
     }
-    // the two units of the next tile's second K-tile whose slots the last K-tile has finished reading:
-    // issued ahead of the stores, so that nothing the next tile needs soon queues behind them
-    issue(TB{}, H1{}, nk + 1, copy ^ 1);
-    issue(TA{}, H1{}, nk + 1, copy ^ 1);
     DPA_TR(48);
 
     // ---- epilogue (no barriers, no LDS-DMA: only stores, counted in the next tile's first waits) ----
