@@ -37,9 +37,14 @@ namespace dpa {
 // XOR-swizzled with the row index: without it the 32 lanes of a half-wave write one bank column (row
 // stride = 128 or 256 bytes), which the bank-conflict counter showed as ~1 conflict cycle per LDS
 // instruction of the whole kernel although the main loop's patterns have none.
+// With rotary tables (rc, rs: fp32 [positions, HS / 2]; rc == nullptr: none) the stored rows are rotated BACK by
+// the angles of position pos0 + row: the tile is a gradient with respect to rotated q or k rows, and what
+// leaves is the gradient with respect to the rows before the rotation (the transpose of a rotation is its
+// inverse). A lane holds 4 whole (even, odd) pairs of one row at that point, once per workgroup.
 template <int HS>
 __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)[HS / 32], float mul, bf16_t* out,
-                                             long long ts, int row0, int nrows, int lane) {
+                                             long long ts, int row0, int nrows, int lane, const float* rc = nullptr,
+                                             const float* rs = nullptr, int pos0 = 0) {
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < HS / 32; ++dt) {
@@ -57,7 +62,16 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
 #pragma unroll
   for (int i = 0; i < 32 * CPR / 64; ++i) {
     const int id = lane + 64 * i, row = id / CPR, ch = id % CPR;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(wave_lds + row * (HS * 2) + (ch ^ (row & (CPR - 1))) * 16);
+    u32x4 v = *reinterpret_cast<const u32x4*>(wave_lds + row * (HS * 2) + (ch ^ (row & (CPR - 1))) * 16);
+    if (rc != nullptr && row0 + row < nrows) {
+      const long long o = (long long)(pos0 + row0 + row) * (HS / 2) + ch * 4;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(rc + o), sn = *reinterpret_cast<const f32x4*>(rs + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float re = lo_bf16(v[j]), im = hi_bf16(v[j]);
+        v[j] = pack_bf16x2(re * c[j] + im * sn[j], im * c[j] - re * sn[j]);
+      }
+    }
     if (row0 + row < nrows) *reinterpret_cast<u32x4*>(out + (long long)(row0 + row) * ts + ch * 8) = v;
   }
 }
@@ -667,7 +681,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   }
   __syncthreads();
   bf16_t* dqp = (bf16_t*)p.dq + b * p.dq_bs + h * HS;
-  store_tile_T<HS>(smem + wave * 32 * HS * 2, dqacc, p.scale, dqp, p.dq_ts, q0 + wave * 32, p.Tq, lane);
+  store_tile_T<HS>(smem + wave * 32 * HS * 2, dqacc, p.scale, dqp, p.dq_ts, q0 + wave * 32, p.Tq, lane, p.rope_cos,
+                   p.rope_sin, p.rope_pos0 + (p.Tk - p.Tq));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -826,7 +841,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   bf16_t* dkp = (bf16_t*)p.dk + b * p.dk_bs + kvh * HS;
   bf16_t* dvp = (bf16_t*)p.dv + b * p.dv_bs + kvh * HS;
   char* wl = smem + wave * 32 * HS * 2;
-  store_tile_T<HS>(wl, dkacc, p.scale, dkp, p.dk_ts, kw0, p.Tk, lane);
+  store_tile_T<HS>(wl, dkacc, p.scale, dkp, p.dk_ts, kw0, p.Tk, lane, p.rope_cos, p.rope_sin, p.rope_pos0);
   store_tile_T<HS>(wl, dvacc, 1.f, dvp, p.dv_ts, kw0, p.Tk, lane);
 }
 

@@ -442,11 +442,30 @@ std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tens
   return {o, lse};
 }
 
+// fp32 [positions, hs / 2] cos / sin tables on the GPU covering positions [0, need)
+void check_rope_tables(const Tensor& c, const Tensor& s, int64_t hs, int64_t need, const char* who) {
+  TORCH_CHECK(c.is_cuda() && s.is_cuda() && c.scalar_type() == at::kFloat && s.scalar_type() == at::kFloat &&
+                  c.dim() == 2 && c.sizes() == s.sizes() && c.is_contiguous() && s.is_contiguous() && c.size(1) * 2 == hs,
+              who, ": rotary tables are contiguous fp32 [positions, hs / 2] on the GPU");
+  TORCH_CHECK(need <= c.size(0), who, ": rotary tables hold ", c.size(0), " positions, ", need, " needed");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(c.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(s.data_ptr()) % 16 == 0,
+              who, ": rotary tables must be 16-byte aligned");
+}
+
 void attn_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
               const Tensor& lse, Tensor dq, Tensor dk, Tensor dv, double scale, double p_drop,
-              const std::optional<Tensor>& seed) {
+              const std::optional<Tensor>& seed, const std::optional<Tensor>& rope_cos,
+              const std::optional<Tensor>& rope_sin, int64_t rope_pos0) {
   dpa::AttnParams p = attn_params(q, k, v, scale);
   set_dropout(p, p_drop, seed);
+  TORCH_CHECK(rope_cos.has_value() == rope_sin.has_value(), "attention backward: both rotary tables or none");
+  if (rope_cos.has_value()) {
+    TORCH_CHECK(rope_pos0 >= 0, "attention backward: rope_pos0 >= 0");
+    check_rope_tables(*rope_cos, *rope_sin, q.size(3), rope_pos0 + k.size(1), "attention backward");
+    p.rope_cos = rope_cos->data_ptr<float>();
+    p.rope_sin = rope_sin->data_ptr<float>();
+    p.rope_pos0 = (int)rope_pos0;
+  }
   const int64_t hs = q.size(3);
   check_heads(dout, "dout", hs);
   check_heads(o, "o", hs);
@@ -912,6 +931,39 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt(const Tensor& a, const Tensor&
   return {c, aux_out};
 }
 
+// c[M, N] = rope(a b^T + bias): the fused qkv projection whose first rope_cols columns (the q and k heads, each hs
+// wide) leave the GEMM already rotated; row r is position pos0 + r % seq_len.
+Tensor gemm_nt_rope(const Tensor& a, const Tensor& b, const std::optional<Tensor>& bias, const Tensor& rope_cos,
+                    const Tensor& rope_sin, int64_t pos0, int64_t seq_len, int64_t rope_cols, int64_t hs) {
+  TORCH_CHECK(gemm_nt_supported(a, b, bias, std::nullopt), "gemm_nt_rope: unsupported operands (see gemm_nt_supported)");
+  const int64_t M = a.size(0), K = a.size(1), N = b.size(0);
+  TORCH_CHECK((hs == 64 || hs == 128) && rope_cols % hs == 0 && rope_cols >= 0 && rope_cols <= N && N % hs == 0,
+              "gemm_nt_rope: heads of 64 or 128 columns, rope_cols a multiple of the head size within N");
+  TORCH_CHECK(seq_len > 0 && pos0 >= 0, "gemm_nt_rope: seq_len > 0, pos0 >= 0");
+  check_rope_tables(rope_cos, rope_sin, hs, pos0 + std::min<int64_t>(seq_len, M), "gemm_nt_rope");
+  Tensor c = at::empty({M, N}, a.options());
+  dpa::GemmNtArgs g{};
+  g.a = a.data_ptr();
+  g.b = b.data_ptr();
+  g.c = c.data_ptr();
+  g.bias = bias.has_value() ? bias->data_ptr() : nullptr;
+  g.M = (int)M;
+  g.N = (int)N;
+  g.K = (int)K;
+  g.lda = a.stride(0);
+  g.ldb = b.stride(0);
+  g.ldc = N;
+  g.ld_aux = N;
+  g.rope_cos = rope_cos.data_ptr<float>();
+  g.rope_sin = rope_sin.data_ptr<float>();
+  g.rope_cols = (int)rope_cols;
+  g.rope_hs = (int)hs;
+  g.rope_T = (int)seq_len;
+  g.rope_pos0 = (int)pos0;
+  dpa::gemm_nt(g, dpa::kEpiRope, gemm_cus(), cur_stream());
+  return c;
+}
+
 // Grouped form of the NT GEMM (csrc/gemm_nt.hip): c[rows, N] = epi(a[rows, K] * W_g^T) with W_g = the [N, K] matrix
 // at address w_ptrs[block_group[row / 256]]. epi: 0 none, 1 GELU (also returns GELU'), 2 multiply by aux [rows, N].
 std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const Tensor& w_ptrs, int64_t N, int64_t ldw,
@@ -1045,7 +1097,10 @@ TORCH_LIBRARY(dpa, m) {
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? kv_len=None) -> (Tensor, Tensor)");
   m.def("attn_dropout_mask(int B, int nh, int Tq, int Tk, float p_drop, Tensor seed) -> Tensor");
   m.def("attn_bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor(a!) dq, Tensor(b!) dk, "
-        "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None) -> ()");
+        "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? rope_cos=None, Tensor? rope_sin=None, "
+        "int rope_pos0=0) -> ()");
+  m.def("gemm_nt_rope(Tensor a, Tensor b, Tensor? bias, Tensor rope_cos, Tensor rope_sin, int pos0, int seq_len, "
+        "int rope_cols, int hs) -> Tensor");
   m.def("rope_(Tensor(a!) x, Tensor cos_t, Tensor sin_t, int pos0, bool inverse) -> ()");
 }
 
@@ -1060,6 +1115,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
 TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("ws_to_many", ws_to_many);
   m.impl("gemm_nt", gemm_nt);
+  m.impl("gemm_nt_rope", gemm_nt_rope);
   m.impl("gemm_nt_into", gemm_nt_into);
   m.impl("gemm_nt_grouped", gemm_nt_grouped);
   m.impl("transpose_bf16", transpose_bf16);

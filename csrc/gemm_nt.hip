@@ -23,7 +23,7 @@
 //    conflict-free for the 16-row x 4-chunk fragment reads.
 //  * Epilogues on the accumulators: + bias (staged once in LDS as fp32); exact-erf GELU that also
 //    emits GELU'(x) for the backward pass; x auxiliary tensor (the dGELU of the backward pass);
-//    + auxiliary tensor (residual).
+//    + auxiliary tensor (residual); rotary embedding of the leading (q, k) columns of a fused qkv projection.
 //
 // Replaces the GEMMs that nn.Linear issues implicitly in the reference
 // (reference: single-gpu/model.py:112-114,153,373-374,388-398,559).
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       const int col0 = cur_n0 + 64 * wc, lim = p.N - col0;   // the wave's 64 columns (unpaired tiles)
       // bias of the lane's 16 columns: as floats, or (forms that also hold the auxiliary pieces in registers)
       // packed as loaded and unpacked at each use
-      constexpr bool kBiasPacked = BIAS && kXpose && (EPI == kEpiMul || EPI == kEpiAdd);
+      constexpr bool kBiasPacked = BIAS && kXpose && (EPI == kEpiMul || EPI == kEpiAdd || EPI == kEpiRope);
       float bv[16];
       u32x4 bp0 = {0u, 0u, 0u, 0u}, bp1 = {0u, 0u, 0u, 0u};
       if (BIAS) {
@@ -651,8 +651,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
             ax[mh][mt][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o2, 0, 0);
           }
       }
+      // Rotary form: the lane's 16 columns are 8 (even, odd) pairs of one head (heads are 64 or 128 wide and
+      // start at multiples of their width, colq is a multiple of 16), the same 8 table columns for every row of
+      // the tile. A wave's 64 columns lie on one side of rope_cols: the test is on scalars, a plain branch.
+      // The lane's rows are 16 apart inside one 128-row block, which never straddles two sequences
+      // (rope_T % 128 == 0): cos / sin of the first row come from the tables, every later row's by the angle
+      // addition with the tables' row 16 (32 registers instead of 128; seven steps in fp32).
+      const bool rot = EPI == kEpiRope && cur_n0 + 64 * wc < p.rope_cols;
+      f32x4 rc[2] = {}, rs[2] = {}, dc[2] = {}, ds[2] = {};   // (defined on both paths: nothing carried across tiles)
+      if (EPI == kEpiRope) {
+        if (rot) {
+          int c0 = (colq & (p.rope_hs - 1)) >> 1;
+          const int half = p.rope_hs >> 1;
+          // opaque: c0 is the same for every tile of a lane, and the step constants loaded from it would
+          // otherwise be hoisted out of the tile loop into registers the K loop has no room for
+          asm volatile("" : "+v"(c0));
+          const unsigned t = (unsigned)(cur_m0 + 128 * wr + l15) % (unsigned)p.rope_T;
+          const long long o = (long long)(p.rope_pos0 + (int)t) * half + c0, o16 = 16ll * half + c0;
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
+          for (int h2 = 0; h2 < 2; ++h2) {
+            rc[h2] = reinterpret_cast<const f32x4*>(p.rope_cos + o)[h2];
+            rs[h2] = reinterpret_cast<const f32x4*>(p.rope_sin + o)[h2];
+            dc[h2] = reinterpret_cast<const f32x4*>(p.rope_cos + o16)[h2];
+            ds[h2] = reinterpret_cast<const f32x4*>(p.rope_sin + o16)[h2];
+          }
+        }
+      }
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int row0 = cur_m0 + 128 * wr + 64 * mh + 16 * mt;
@@ -663,6 +689,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
           for (int T = 0; T < 4; ++T)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * T + e] = acc[mh][mt][T][e] + bias_at(4 * T + e);
+          if (EPI == kEpiRope) {
+            if (rot) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float c = rc[j >> 2][j & 3], sn = rs[j >> 2][j & 3];
+                const float re = v[2 * j], im = v[2 * j + 1];
+                v[2 * j] = re * c - im * sn;
+                v[2 * j + 1] = re * sn + im * c;
+                rc[j >> 2][j & 3] = c * dc[j >> 2][j & 3] - sn * ds[j >> 2][j & 3];
+                rs[j >> 2][j & 3] = sn * dc[j >> 2][j & 3] + c * ds[j >> 2][j & 3];
+              }
+            }
+          }
           if (EPI == kEpiMul || EPI == kEpiAdd) {
             u32x4 x0, x1;
             if (kAuxX) {
@@ -771,6 +810,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
           }
           store_rows16(rsC, o0, o1, row0, col0, lim, (unsigned)p.ldc);
         }
+      }
     }
     DPA_TR(49);
     if (kLateBarrier && wr == 1) barrier();
@@ -862,7 +902,7 @@ void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   static bool attr = false;
 #define DPA_GNT_ALL(F)                                                                  \
   F(kEpiNone, false) F(kEpiNone, true) F(kEpiGelu, false) F(kEpiGelu, true) F(kEpiMul, false) F(kEpiMul, true) \
-  F(kEpiAdd, false) F(kEpiAdd, true) F(kEpiSwiglu, false) F(kEpiDswiglu, false)
+  F(kEpiAdd, false) F(kEpiAdd, true) F(kEpiSwiglu, false) F(kEpiDswiglu, false) F(kEpiRope, false) F(kEpiRope, true)
   if (!attr) {
 #define DPA_GNT_ATTR(E, B)                                                                                        \
   (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, B, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); \

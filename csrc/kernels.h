@@ -77,6 +77,11 @@ struct AttnParams {
   // Forward only: number of valid keys read from device memory (<= Tk, the allocated length). Lets a
   // captured decode step run over a preallocated KV cache whose fill level changes between replays.
   const int* kv_len;
+  // Backward only, optional: q and k were rotated (interleaved-pair rotary embedding, fp32 tables
+  // [positions, hs / 2]) after the projection that the gradients go back to, row t by the angles of position
+  // rope_pos0 + t: dq and dk are rotated back as they are stored.
+  const float *rope_cos, *rope_sin;
+  int rope_pos0;
 };
 void attn_fwd(const AttnParams& p, hipStream_t st);
 void attn_bwd(const AttnParams& p, hipStream_t st);
@@ -124,9 +129,12 @@ void wgrad_finish_many(const float* ws, const long long* dst_ptrs, int count, lo
 //                 pass. An output tile pairs 128 gate with the 128 matching up columns inside each lane.
 //   kEpiDswiglu : c[M, 2N] (row stride ldc) = [v * up * silu'(gate) | v * silu(gate)] with [gate | up] =
 //                 aux_in[M, 2N] (row stride ld_aux): the input gradient of the SwiGLU from v = dy W_proj.
+//   kEpiRope : c = v with the interleaved pairs (2j, 2j + 1) of every rope_hs-wide head in columns
+//                 [0, rope_cols) rotated by the angles of position rope_pos0 + row % rope_T (rotary embedding of
+//                 the q and k heads of a fused qkv projection; tables rope_cos / rope_sin fp32 [positions, rope_hs / 2])
 // K % 64 == 0, K >= 128, N % 16 == 0, rows 16-byte aligned, every tensor below 4 GB - 16 MB,
 // bias only for N <= 8192 (gemm_nt_ok checks all of it).
-enum { kEpiNone = 0, kEpiGelu = 1, kEpiMul = 2, kEpiAdd = 3, kEpiSwiglu = 4, kEpiDswiglu = 5 };
+enum { kEpiNone = 0, kEpiGelu = 1, kEpiMul = 2, kEpiAdd = 3, kEpiSwiglu = 4, kEpiDswiglu = 5, kEpiRope = 6 };
 struct GemmNtArgs {
   const void *a, *b;
   void* c;
@@ -144,6 +152,9 @@ struct GemmNtArgs {
   const long long* w_ptrs;
   const int* block_group;
   int ngroups;
+  // kEpiRope only: rope_hs in {64, 128}, rope_cols % rope_hs == 0, rope_T > 0, tables of at least rope_pos0 + rope_T rows
+  const float *rope_cos, *rope_sin;
+  int rope_cols, rope_hs, rope_T, rope_pos0;
 };
 bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,
                 bool has_bias);

@@ -161,6 +161,13 @@ class GQA(nn.Module):
         B, T, C = x.shape
         nh, nkv, hs = self.config.n_head, self.config.n_kv_heads, self.head_size
         p_drop = self.config.dropout if self.training else 0.0
+        if (rope is not None and kv_cache is None and not self._want_cache()
+                and ops.qkv_rope_attention_supported(x, self.c_attn.weight, self.c_attn.bias, rope[0], rope[1], int(rope[2]), hs)):
+            # training path: the rotation is the projection GEMM's epilogue, its inverse on dq / dk the attention
+            # backward kernels' store; no rotary pass over the activations in either direction
+            y = ops.qkv_rope_attention(x, self.c_attn.weight, self.c_attn.bias, rope[0], rope[1], int(rope[2]), nh, nkv,
+                                       dropout_p=p_drop, sole_use=True).reshape(B, T, C)
+            return self._project(y, residual), None
         qkv = ops.linear(x, self.c_attn.weight, self.c_attn.bias, sole_use=True)
         if rope is not None:
             # rotate the q and k heads (contiguous leading part of the fused projection)
@@ -183,11 +190,13 @@ class GQA(nn.Module):
                 v = torch.cat((past_v.transpose(1, 2), v), dim=1)
             y = ops.causal_attention(q, k, v, dropout_p=p_drop)
             new_cache = (k.transpose(1, 2), v.transpose(1, 2))  # reference cache shape (B, nkv, T, hs)
-        y = y.reshape(B, T, C)
+        return self._project(y.reshape(B, T, C), residual), new_cache
+
+    def _project(self, y, residual):
         if residual is not None and not (self.training and self.config.dropout > 0.0):
-            return ops.linear(y, self.c_proj.weight, self.c_proj.bias, sole_use=True, residual=residual), new_cache
+            return ops.linear(y, self.c_proj.weight, self.c_proj.bias, sole_use=True, residual=residual)
         y = _drop(ops.linear(y, self.c_proj.weight, self.c_proj.bias, sole_use=True), self.config.dropout, self.training)
-        return (y if residual is None else residual + y), new_cache
+        return y if residual is None else residual + y
 
     def _want_cache(self) -> bool:
         # The training / validation path never reads the returned cache; building it would only

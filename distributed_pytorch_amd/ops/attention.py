@@ -137,6 +137,74 @@ def causal_self_attention_qkv(qkv: torch.Tensor, nh: int, nkv: int, scale: float
     return causal_attention_eager(q, k, v, float(scale), dropout_p)
 
 
+class _QkvRopeAttnFn(torch.autograd.Function):
+    """Self-attention block front end with rotary embedding, without a rotation pass of its own:
+    ``o = attention(rope(x W^T + b))``. The projection GEMM rotates the q and k columns in its epilogue
+    (``gemm_nt_rope``), and the attention backward kernels rotate dq and dk back as they store them, so the
+    fused gradient buffer that reaches the projection's backward GEMMs is already the gradient of the
+    unrotated projection (reference: single-gpu/model.py:77-96,130-133)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cos_t, sin_t, pos0, nh, nkv, hs, scale, dropout_p, sole_use):
+        x2 = x.reshape(-1, x.shape[-1])
+        B, T = x.shape[0], x.shape[1]
+        qkv = ops().gemm_nt_rope(x2, w, b, cos_t, sin_t, pos0, T, (nh + nkv) * hs, hs).view(B, T, -1)
+        q, k, v = split_qkv(qkv, nh, nkv)
+        seed = _draw_seed(dropout_p, x.device)
+        o, lse = ops().attn_fwd(q, k, v, scale, dropout_p, seed)
+        ctx.save_for_backward(x, w, qkv, o, lse, seed, cos_t, sin_t)
+        ctx.cfg = (pos0, nh, nkv, scale, dropout_p)
+        ctx.has_bias = b is not None
+        ctx.w_param = w if sole_use else None
+        ctx.b_param = b if sole_use else None
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        from .linear import _input_grad, _param_grads
+        x, w, qkv, o, lse, seed, cos_t, sin_t = ctx.saved_tensors
+        pos0, nh, nkv, scale, dropout_p = ctx.cfg
+        q, k, v = split_qkv(qkv, nh, nkv)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = split_qkv(dqkv, nh, nkv)
+        ops().attn_bwd(_packed(do), q, k, v, o, lse, dq, dk, dv, scale, dropout_p, seed, cos_t, sin_t, pos0)
+        d2 = dqkv.view(-1, dqkv.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = _input_grad(d2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dw, db = _param_grads(ctx.w_param, ctx.b_param, d2, x2, ctx.needs_input_grad[1], need_b)
+        return (dx, dw, db) + (None,) * 9
+
+
+def qkv_rope_attention_supported(x: torch.Tensor, w: torch.Tensor, b, cos_t: torch.Tensor, sin_t: torch.Tensor,
+                                 pos0: int, hs: int) -> bool:
+    """Shapes the fused projection + rotary + attention path takes: bf16 on the GPU, head size 64 or 128,
+    sequences of a multiple of 128 tokens (a 128-row block of the GEMM's output tile must not straddle two
+    sequences), tables that cover the positions (and row 16, the step of the epilogue's angle addition)."""
+    import os
+    from .linear import gemm_supported
+    if not (use_hip(x, w, cos_t, sin_t) and x.dim() == 3 and x.dtype == torch.bfloat16 and hs in (64, 128)):
+        return False
+    if os.environ.get("DPA_FUSED_ROPE", "1") == "0" or not hasattr(ops(), "gemm_nt_rope"):
+        return False
+    T = x.shape[1]
+    if T % 128 != 0 or cos_t.dtype != torch.float32 or sin_t.dtype != torch.float32 or cos_t.shape != sin_t.shape:
+        return False
+    if not (cos_t.dim() == 2 and cos_t.is_contiguous() and sin_t.is_contiguous() and cos_t.shape[1] * 2 == hs
+            and cos_t.shape[0] >= max(pos0 + T, 17) and cos_t.data_ptr() % 16 == 0 and sin_t.data_ptr() % 16 == 0):
+        return False
+    return w.shape[0] % hs == 0 and gemm_supported(x.reshape(-1, x.shape[-1]), w, b)
+
+
+def qkv_rope_attention(x: torch.Tensor, w: torch.Tensor, b, cos_t: torch.Tensor, sin_t: torch.Tensor, pos0: int,
+                       nh: int, nkv: int, dropout_p: float = 0.0, sole_use: bool = False) -> torch.Tensor:
+    """``x [B, T, C]`` -> ``o [B, T, nh, hs]`` = causal attention over the rotary-embedded fused projection
+    ``x w^T + b`` (``w [(nh + 2 nkv) hs, C]``); callers check ``qkv_rope_attention_supported`` first."""
+    hs = w.shape[0] // (nh + 2 * nkv)
+    return _QkvRopeAttnFn.apply(x, w, b, cos_t, sin_t, int(pos0), nh, nkv, hs, 1.0 / math.sqrt(hs), float(dropout_p),
+                                sole_use)
+
+
 def causal_attention_eager(q, k, v, scale: float, dropout_p: float = 0.0) -> torch.Tensor:
     B, Tq, nh, hs = q.shape
     Tk, nkv = k.shape[1], k.shape[2]

@@ -1032,3 +1032,64 @@ def test_grouped_wgrad_on_the_256_kernel_matches():
         s, n = int(start[g]), int(seg[g])
         want = dy[s:s + n].float().t() @ x[s:s + n].float()
         assert (got[g] - want).abs().max() <= 1e-3 * max(want.abs().max().item(), 1.0), g
+
+
+@pytest.mark.parametrize("B,T,nh,nkv,hs,C,pos0,bias", [(4, 128, 4, 2, 64, 256, 0, True), (3, 256, 6, 6, 128, 768, 0, False),
+                                                       (5, 128, 12, 4, 64, 768, 100, True), (2, 1024, 12, 12, 64, 768, 0, True)])
+def test_gemm_nt_rope_epilogue_matches_fp32_rotation(B, T, nh, nkv, hs, C, pos0, bias):
+    """The qkv projection with the rotary embedding in its epilogue against an fp32 product followed by the
+    eager fp32 rotation of the q and k heads; the v columns are the plain product."""
+    from distributed_pytorch_amd.ops.rope import _rope_eager, rope_tables
+    torch.manual_seed(0)
+    W = (nh + 2 * nkv) * hs
+    cos_t, sin_t = rope_tables(pos0 + T + 3, hs, device="cuda")
+    x = torch.randn(B * T, C, device="cuda").bfloat16()
+    w = (torch.randn(W, C, device="cuda") / math.sqrt(C)).bfloat16()
+    b = torch.randn(W, device="cuda").bfloat16() if bias else None
+    got = _ops().gemm_nt_rope(x, w, b, cos_t, sin_t, pos0, T, (nh + nkv) * hs, hs)
+    ref = x.float() @ w.float().t() + (b.float() if bias else 0.0)
+    rq = _rope_eager(ref[:, : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, pos0, False)
+    ref = torch.cat([rq.reshape(B * T, -1), ref[:, (nh + nkv) * hs:]], dim=1)
+    assert rel_err(got, ref) < 6e-3
+    assert torch.allclose(got.float(), ref, atol=3e-2, rtol=2e-2)
+    plain = _ops().gemm_nt(x, w, b, 0, None)[0]
+    assert torch.equal(got[:, (nh + nkv) * hs:], plain[:, (nh + nkv) * hs:])
+
+
+@pytest.mark.parametrize("nh,nkv,hs", [(4, 2, 64), (6, 6, 128)])
+def test_qkv_rope_attention_fused_matches_separate_passes(nh, nkv, hs):
+    """Projection + rotary + attention with the rotation inside the GEMM epilogue and its inverse inside
+    the attention backward stores, against the same block with separate rotary passes, and against fp32."""
+    from distributed_pytorch_amd import ops
+    from distributed_pytorch_amd.ops.rope import _rope_eager, rope_tables
+    torch.manual_seed(1)
+    B, T, C = 4, 256, nh * hs
+    W = (nh + 2 * nkv) * hs
+    cos_t, sin_t = rope_tables(T, hs, device="cuda")
+    x0 = torch.randn(B, T, C, device="cuda").bfloat16()
+    w0 = (torch.randn(W, C, device="cuda") / math.sqrt(C)).bfloat16()
+    b0 = (torch.randn(W, device="cuda") * 0.1).bfloat16()
+    do = torch.randn(B, T, nh, hs, device="cuda").bfloat16()
+    assert ops.qkv_rope_attention_supported(x0, w0, b0, cos_t, sin_t, 0, hs)
+
+    def run(kind):
+        dt = torch.float32 if kind == "fp32" else torch.bfloat16
+        x, w, b = [t.detach().to(dt).requires_grad_() for t in (x0, w0, b0)]
+        if kind == "fused":
+            o = ops.qkv_rope_attention(x, w, b, cos_t, sin_t, 0, nh, nkv)
+        elif kind == "separate":
+            qkv = ops.rope_qkv_(ops.linear(x, w, b), cos_t, sin_t, 0, nh + nkv, hs)
+            o = ops.causal_self_attention_qkv(qkv, nh, nkv)
+        else:
+            qkv = F.linear(x, w, b)
+            qk = _rope_eager(qkv[..., : (nh + nkv) * hs].reshape(B, T, nh + nkv, hs), cos_t, sin_t, 0, False)
+            q, k, v = qk[:, :, :nh], qk[:, :, nh:], qkv[..., (nh + nkv) * hs:].reshape(B, T, nkv, hs)
+            o = ops.causal_attention_eager(q, k, v, 1.0 / math.sqrt(hs))
+        o.backward(do.to(dt))
+        return o, x.grad, w.grad, b.grad
+
+    fused, sep, ref = run("fused"), run("separate"), run("fp32")
+    for name, f, s, r in zip(("o", "dx", "dw", "db"), fused, sep, ref):
+        assert rel_err(f, r) < 2e-2, name
+        assert rel_err(f, s) < 2e-2, name
+        assert rel_err(f, r) < 1.5 * rel_err(s, r) + 2e-3, name   # one rounding fewer, never less accurate
