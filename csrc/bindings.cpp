@@ -304,7 +304,7 @@ Tensor gelu_bwd(const Tensor& dy, const Tensor& x) {
   dpa::gelu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), is_bf16(x), cur_stream());
   return dx;
 }
-Tensor sample_topk(const Tensor& logits, double temperature, int64_t topk, const Tensor& seed) {
+void check_sample_args(const Tensor& logits, const Tensor& seed) {
   TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && logits.stride(1) == 1 &&
                   (logits.scalar_type() == at::kBFloat16 || logits.scalar_type() == at::kFloat),
               "sample_topk: logits [rows, V] bf16/fp32 with unit inner stride on the GPU");
@@ -313,11 +313,41 @@ Tensor sample_topk(const Tensor& logits, double temperature, int64_t topk, const
                   (logits.stride(0) * logits.element_size()) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(logits.data_ptr()) % 16 == 0,
               "sample_topk: vocabulary must be a multiple of 8, at most 57344, rows 16-byte aligned");
+}
+
+Tensor sample_topk(const Tensor& logits, double temperature, int64_t topk, const Tensor& seed) {
+  check_sample_args(logits, seed);
   Tensor out = at::empty({logits.size(0), 1}, logits.options().dtype(at::kLong));
   dpa::sample_topk(logits.data_ptr(), logits.stride(0), (int)logits.size(0), (int)logits.size(1), (float)temperature,
                    (int)std::max<int64_t>(topk, 0), (const long long*)seed.data_ptr<int64_t>(),
                    (long long*)out.data_ptr<int64_t>(), is_bf16(logits), cur_stream());
   return out;
+}
+
+// Sampling plus the bookkeeping of one captured decode step: the token goes to `tok` [rows, 1] (the next step's
+// input) and to history[:, history_pos]; pos, len_after and history_pos then advance by one (see SampleStep).
+void sample_topk_step(const Tensor& logits, double temperature, int64_t topk, const Tensor& seed, Tensor tok,
+                      Tensor history, Tensor history_pos, Tensor pos, Tensor len_after, Tensor ticket) {
+  check_sample_args(logits, seed);
+  const int64_t rows = logits.size(0);
+  auto scalar = [](const Tensor& t, at::ScalarType ty) { return t.is_cuda() && t.scalar_type() == ty && t.numel() == 1; };
+  TORCH_CHECK(tok.is_cuda() && tok.scalar_type() == at::kLong && tok.is_contiguous() && tok.numel() == rows,
+              "sample_topk_step: tok is contiguous int64 [rows, 1] on the GPU");
+  TORCH_CHECK(history.is_cuda() && history.scalar_type() == at::kLong && history.dim() == 2 && history.size(0) == rows &&
+                  history.stride(1) == 1,
+              "sample_topk_step: history is int64 [rows, steps] on the GPU");
+  TORCH_CHECK(scalar(history_pos, at::kLong) && scalar(pos, at::kLong) && scalar(len_after, at::kInt) && scalar(ticket, at::kInt),
+              "sample_topk_step: history_pos / pos int64 [1], len_after / ticket int32 [1], on the GPU");
+  dpa::SampleStep st;
+  st.history = (long long*)history.data_ptr<int64_t>();
+  st.history_ld = history.stride(0);
+  st.history_pos = (long long*)history_pos.data_ptr<int64_t>();
+  st.pos = (long long*)pos.data_ptr<int64_t>();
+  st.len_after = len_after.data_ptr<int>();
+  st.ticket = (unsigned*)ticket.data_ptr<int>();
+  dpa::sample_topk(logits.data_ptr(), logits.stride(0), (int)rows, (int)logits.size(1), (float)temperature,
+                   (int)std::max<int64_t>(topk, 0), (const long long*)seed.data_ptr<int64_t>(),
+                   (long long*)tok.data_ptr<int64_t>(), is_bf16(logits), cur_stream(), st);
 }
 
 void spin(int64_t blocks, int64_t usec, Tensor sink) {
@@ -964,6 +994,84 @@ Tensor gemm_nt_rope(const Tensor& a, const Tensor& b, const std::optional<Tensor
   return c;
 }
 
+// Decode-step linear layer (csrc/decode.hip): y [B, N] = act(LN(x) w^T + bias) + residual, B <= 16. With the KV caches
+// given (contiguous [B, S, heads, hs], row width kv_cols = heads * hs), the output columns from kv_col0 on are the
+// new key and value rows and go to row `pos` of the caches; y then holds only the columns below kv_col0.
+bool decode_linear_supported(const Tensor& x, const Tensor& w, int64_t act, bool has_ln) {
+  if (!x.is_cuda() || !w.is_cuda() || x.dim() != 2 || w.dim() != 2) return false;
+  if (x.scalar_type() != at::kBFloat16 || w.scalar_type() != at::kBFloat16) return false;
+  if (x.stride(1) != 1 || w.stride(1) != 1 || x.size(1) != w.size(1)) return false;
+  if (reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 || reinterpret_cast<uintptr_t>(w.data_ptr()) % 16) return false;
+  const bool pair = act == dpa::kDecodeSwiglu;
+  if (pair && w.size(0) % 2) return false;
+  const int64_t N = pair ? w.size(0) / 2 : w.size(0);
+  return dpa::decode_linear_ok(x.size(0), N, x.size(1), x.stride(0), w.stride(0), pair, has_ln);
+}
+
+Tensor decode_linear(const Tensor& x, const std::optional<Tensor>& ln_w, const std::optional<Tensor>& ln_b, double eps,
+                     const Tensor& w, const std::optional<Tensor>& bias, const std::optional<Tensor>& residual, int64_t act,
+                     const std::optional<Tensor>& k_cache, const std::optional<Tensor>& v_cache,
+                     const std::optional<Tensor>& pos, int64_t kv_col0) {
+  TORCH_CHECK(act >= 0 && act <= 2, "decode_linear: act 0 (none), 1 (GELU), 2 (SwiGLU)");
+  TORCH_CHECK(decode_linear_supported(x, w, act, ln_w.has_value()),
+              "decode_linear: unsupported operands (see decode_linear_supported)");
+  const bool pair = act == dpa::kDecodeSwiglu;
+  const int64_t B = x.size(0), K = x.size(1), N = pair ? w.size(0) / 2 : w.size(0);
+  auto vec_ok = [&](const std::optional<Tensor>& t, int64_t n) {
+    return !t.has_value() || (t->is_cuda() && t->scalar_type() == at::kBFloat16 && t->is_contiguous() && t->numel() == n &&
+                              reinterpret_cast<uintptr_t>(t->data_ptr()) % 16 == 0);
+  };
+  TORCH_CHECK(vec_ok(ln_w, K) && vec_ok(ln_b, K) && (!ln_b.has_value() || ln_w.has_value()),
+              "decode_linear: LayerNorm weight / bias are contiguous bf16 [K]");
+  TORCH_CHECK(vec_ok(bias, w.size(0)), "decode_linear: bias is contiguous bf16 [rows of w]");
+  dpa::DecodeLinearArgs p{};
+  p.x = x.data_ptr();
+  p.ldx = x.stride(0);
+  p.ln_w = ln_w.has_value() ? ln_w->data_ptr() : nullptr;
+  p.ln_b = ln_b.has_value() ? ln_b->data_ptr() : nullptr;
+  p.eps = (float)eps;
+  p.w = w.data_ptr();
+  p.ldw = w.stride(0);
+  p.bias = bias.has_value() ? bias->data_ptr() : nullptr;
+  p.B = (int)B;
+  p.N = (int)N;
+  p.K = (int)K;
+  p.act = (int)act;
+  int64_t y_cols = N;
+  if (k_cache.has_value()) {
+    TORCH_CHECK(v_cache.has_value() && pos.has_value() && !pair, "decode_linear: k_cache, v_cache and pos come together");
+    TORCH_CHECK(k_cache->is_cuda() && k_cache->scalar_type() == at::kBFloat16 && k_cache->is_contiguous() &&
+                    k_cache->dim() == 4 && v_cache->is_cuda() && v_cache->scalar_type() == at::kBFloat16 &&
+                    v_cache->is_contiguous() && v_cache->sizes() == k_cache->sizes() && k_cache->size(0) == B,
+                "decode_linear: caches are contiguous bf16 [B, S, heads, hs]");
+    const int64_t kv_cols = k_cache->size(2) * k_cache->size(3);
+    TORCH_CHECK(kv_col0 >= 0 && kv_col0 % 16 == 0 && kv_cols % 16 == 0 && kv_col0 + 2 * kv_cols == N,
+                "decode_linear: the projection is [q | k | v] with k and v as wide as a cache row");
+    TORCH_CHECK(pos->is_cuda() && pos->scalar_type() == at::kLong && pos->numel() == 1, "decode_linear: pos is int64 [1] on the GPU");
+    p.k_cache = k_cache->data_ptr();
+    p.v_cache = v_cache->data_ptr();
+    p.cache_bs = k_cache->stride(0);
+    p.pos = (const long long*)pos->data_ptr<int64_t>();
+    p.kv_col0 = (int)kv_col0;
+    p.kv_cols = (int)kv_cols;
+    y_cols = kv_col0;
+  }
+  Tensor y = at::empty({B, std::max<int64_t>(y_cols, 1)}, x.options());
+  if (residual.has_value()) {
+    TORCH_CHECK(residual->is_cuda() && residual->scalar_type() == at::kBFloat16 && residual->dim() == 2 &&
+                    residual->size(0) == B && residual->size(1) == N && residual->stride(1) == 1 &&
+                    residual->stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(residual->data_ptr()) % 8 == 0 &&
+                    !k_cache.has_value(),
+                "decode_linear: residual is bf16 [B, N] with 8-byte aligned rows");
+    p.residual = residual->data_ptr();
+    p.ldr = residual->stride(0);
+  }
+  p.y = y.data_ptr();
+  p.ldy = y.stride(0);
+  dpa::decode_linear(p, cur_stream());
+  return y;
+}
+
 // Grouped form of the NT GEMM (csrc/gemm_nt.hip): c[rows, N] = epi(a[rows, K] * W_g^T) with W_g = the [N, K] matrix
 // at address w_ptrs[block_group[row / 256]]. epi: 0 none, 1 GELU (also returns GELU'), 2 multiply by aux [rows, N].
 std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const Tensor& w_ptrs, int64_t N, int64_t ldw,
@@ -1089,6 +1197,8 @@ TORCH_LIBRARY(dpa, m) {
   m.def("gelu_bwd(Tensor dy, Tensor x) -> Tensor");
   m.def("kv_append(Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor k_new, Tensor v_new, Tensor pos) -> ()");
   m.def("sample_topk(Tensor logits, float temperature, int topk, Tensor seed) -> Tensor");
+  m.def("sample_topk_step(Tensor logits, float temperature, int topk, Tensor seed, Tensor(a!) tok, Tensor(b!) history, "
+        "Tensor(c!) history_pos, Tensor(d!) pos, Tensor(e!) len_after, Tensor(f!) ticket) -> ()");
   m.def("spin(int blocks, int usec, Tensor(a!) sink) -> ()");
   m.def("act_fwd(Tensor x, int kind) -> Tensor");
   m.def("act_bwd(Tensor dy, Tensor x, int kind) -> Tensor");
@@ -1099,6 +1209,9 @@ TORCH_LIBRARY(dpa, m) {
   m.def("attn_bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor(a!) dq, Tensor(b!) dk, "
         "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? rope_cos=None, Tensor? rope_sin=None, "
         "int rope_pos0=0) -> ()");
+  m.def("decode_linear(Tensor x, Tensor? ln_w, Tensor? ln_b, float eps, Tensor w, Tensor? bias, Tensor? residual, int act, "
+        "Tensor(a!)? k_cache, Tensor(b!)? v_cache, Tensor? pos, int kv_col0) -> Tensor");
+  m.def("decode_linear_supported(Tensor x, Tensor w, int act, bool has_ln) -> bool");
   m.def("gemm_nt_rope(Tensor a, Tensor b, Tensor? bias, Tensor rope_cos, Tensor rope_sin, int pos0, int seq_len, "
         "int rope_cols, int hs) -> Tensor");
   m.def("rope_(Tensor(a!) x, Tensor cos_t, Tensor sin_t, int pos0, bool inverse) -> ()");
@@ -1109,6 +1222,7 @@ TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
   m.impl("gemm_nt_set_variant", [](int64_t v) { dpa::gemm_nt_set_variant((int)v); });
   m.impl("grouped_wgrad_use_wgrad3", [](bool on, bool any_size) { grouped_wgrad_use_wgrad3(on, any_size); });
   m.impl("gemm_nt_supported", gemm_nt_supported);
+  m.impl("decode_linear_supported", decode_linear_supported);
   m.impl("gemm_nt_pair_supported", gemm_nt_pair_supported);
 }
 
@@ -1116,6 +1230,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("ws_to_many", ws_to_many);
   m.impl("gemm_nt", gemm_nt);
   m.impl("gemm_nt_rope", gemm_nt_rope);
+  m.impl("decode_linear", decode_linear);
   m.impl("gemm_nt_into", gemm_nt_into);
   m.impl("gemm_nt_grouped", gemm_nt_grouped);
   m.impl("transpose_bf16", transpose_bf16);
@@ -1149,6 +1264,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("gelu_bwd", gelu_bwd);
   m.impl("kv_append", kv_append);
   m.impl("sample_topk", sample_topk);
+  m.impl("sample_topk_step", sample_topk_step);
   m.impl("spin", spin);
   m.impl("act_fwd", act_fwd);
   m.impl("act_bwd", act_bwd);

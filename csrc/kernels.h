@@ -167,6 +167,36 @@ void gemm_nt_set_variant(int v);   // benchmark knob, see csrc/gemm_nt.hip
 // out[C, R] = in[R, C]^T (bf16, R % 8 == 0 and C % 8 == 0, contiguous).
 void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
 
+// ---- Decode-step linear layer (csrc/decode.hip) ------------------------------------------------------
+// y[B, N] = act(LN(x)[B, K] * w[N, K]^T + bias) + residual for B <= 16 rows (bf16, fp32 accumulation), one launch.
+//   ln_w == nullptr: no LayerNorm (ln_b may be nullptr with ln_w set: no shift)
+//   act kDecodeSwiglu: w is [2N, K] (gate rows, then up rows), bias [2N]: y = silu(gate) * up
+//   k_cache != nullptr: output columns [kv_col0, kv_col0 + kv_cols) go to row *pos of k_cache [B, S, kv_cols]
+//   (batch stride cache_bs elements), the next kv_cols columns to v_cache; columns below kv_col0 to y.
+// N % 16 == 0, K % 128 == 0 (K <= 2048 with the LayerNorm), kv_col0 % 16 == 0, kv_cols % 16 == 0 (decode_linear_ok
+// checks the sizes).
+enum { kDecodeNone = 0, kDecodeGelu = 1, kDecodeSwiglu = 2 };
+struct DecodeLinearArgs {
+  const void* x;
+  long long ldx;
+  const void *ln_w, *ln_b;
+  float eps;
+  const void* w;
+  long long ldw;
+  const void* bias;
+  const void* residual;
+  long long ldr;
+  void* y;
+  long long ldy;
+  int B, N, K, act;
+  void *k_cache, *v_cache;
+  long long cache_bs;
+  const long long* pos;
+  int kv_col0, kv_cols;
+};
+bool decode_linear_ok(long long B, long long N, long long K, long long ldx, long long ldw, bool pair, bool has_ln);
+void decode_linear(const DecodeLinearArgs& p, hipStream_t st);
+
 // ---- Grouped GEMM (MoE experts) ----------------------------------------------------------------
 // c[rows, N] = a[rows, K] * W_g, one weight matrix per 128-row block (block_group[rb]; values outside
 // [0, ngroups) skip the block). w_is_kn = false: W_g is [N, K]; true: W_g is [K, N]. K % 64 == 0,
@@ -205,8 +235,19 @@ void colsum(const void* x, float* out, long long M, int N, long long ld, bool is
 // (topk <= 0: no restriction; temperature <= 0: 1). The uniform variate comes from a hash of *seed and the row.
 // V % 8 == 0, V <= 57344 (sample_topk_ok), rows 16-byte aligned.
 bool sample_topk_ok(int V);
+// Optional bookkeeping of a captured decode step (all pointers to device memory, all null: plain sampling):
+// history[row, *history_pos] = token; then, once every row is done, *pos += 1, *len_after += 1, *history_pos += 1.
+// *pos is also mixed into the random stream, so one seed serves a whole generation. ticket: a zeroed counter.
+struct SampleStep {
+  long long* history = nullptr;
+  long long history_ld = 0;
+  long long* history_pos = nullptr;
+  long long* pos = nullptr;
+  int* len_after = nullptr;
+  unsigned* ticket = nullptr;
+};
 void sample_topk(const void* logits, long long ld, int rows, int V, float temperature, int topk, const long long* seed,
-                 long long* out, bool is_bf16, hipStream_t st);
+                 long long* out, bool is_bf16, hipStream_t st, SampleStep step = SampleStep{});
 // Benchmark aid: occupy `blocks` CUs for about `usec` microseconds.
 void spin(int blocks, int usec, float* sink, hipStream_t st);
 

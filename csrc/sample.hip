@@ -9,6 +9,9 @@
 //      walk of the one thread's registers in which u * total falls (u uniform in [0, 1) from a hash of the
 //      seed and the row). The order of the walk is a fixed permutation of the vocabulary, which a
 //      multinomial draw does not care about.
+// Decode-step form (SampleStep): the kernel also records the token in the generation's history at the device-side
+// column, and the last workgroup to finish advances the step's device counters (cache position, fill level,
+// history column), so a captured decode step needs no bookkeeping launches and no per-step seed draw.
 // Replaces the topk / masked_fill / softmax / multinomial chain of the reference's generate()
 // (reference: single-gpu/model.py:733-745) with a single launch inside the captured decode step.
 #include "common.h"
@@ -52,7 +55,7 @@ template <typename T>
 __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __restrict__ logits, long long ld, int V,
                                                                     float inv_temp, int topk,
                                                                     const long long* __restrict__ seed,
-                                                                    long long* __restrict__ out) {
+                                                                    long long* __restrict__ out, SampleStep step) {
   __shared__ float red[16];
   __shared__ int ired[16];
   __shared__ float wave_tot[kSampleThreads / 64];
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __
     total += wave_tot[w];
   }
   const float excl = base + incl - s;
-  const unsigned long long sd = (unsigned long long)*seed;
+  // decode-step form: the seed is fixed for the whole generation and the position counter makes the draws differ
+  const unsigned long long sd = (unsigned long long)*seed + (step.pos != nullptr ? 0x9E3779B97F4A7C15ull * (unsigned long long)*step.pos : 0ull);
   const unsigned h = smix32((unsigned)sd ^ smix32((unsigned)(sd >> 32) + 0x9E3779B9u * (unsigned)(row + 1)));
   const float target = (float)(h >> 8) * (1.0f / 16777216.0f) * total;   // u in [0, 1) with 24 random bits
   if (s > 0.f && target >= excl && target < excl + s) {
@@ -172,22 +176,40 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __
         }
       }
     }
-    out[row] = pick >= 0 ? pick : last;
+    const long long token = pick >= 0 ? pick : last;
+    out[row] = token;
+    if (step.history != nullptr) step.history[(long long)row * step.history_ld + *step.history_pos] = token;
+  }
+  if (step.ticket != nullptr) {
+    // The step's counters move once every row has read them: the last workgroup to get here does it.
+    __shared__ unsigned arrived;
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      arrived = atomicAdd(step.ticket, 1u);
+    }
+    __syncthreads();
+    if (arrived == gridDim.x - 1 && tid == 0) {
+      *step.pos += 1;
+      *step.len_after += 1;
+      *step.history_pos += 1;
+      *step.ticket = 0u;
+    }
   }
 }
 
 bool sample_topk_ok(int V) { return V >= 8 && V % 8 == 0 && V <= kSampleThreads * kSampleVecs * 8; }
 
 void sample_topk(const void* logits, long long ld, int rows, int V, float temperature, int topk, const long long* seed,
-                 long long* out, bool is_bf16, hipStream_t st) {
+                 long long* out, bool is_bf16, hipStream_t st, SampleStep step) {
   if (rows == 0) return;
   const float inv_temp = temperature > 0.f ? 1.f / temperature : 1.f;
   if (is_bf16)
     hipLaunchKernelGGL((sample_topk_kernel<bf16_t>), dim3(rows), dim3(kSampleThreads), 0, st, (const bf16_t*)logits, ld, V,
-                       inv_temp, topk, seed, out);
+                       inv_temp, topk, seed, out, step);
   else
     hipLaunchKernelGGL((sample_topk_kernel<float>), dim3(rows), dim3(kSampleThreads), 0, st, (const float*)logits, ld, V,
-                       inv_temp, topk, seed, out);
+                       inv_temp, topk, seed, out, step);
 }
 
 }  // namespace dpa

@@ -1093,3 +1093,86 @@ def test_qkv_rope_attention_fused_matches_separate_passes(nh, nkv, hs):
         assert rel_err(f, r) < 2e-2, name
         assert rel_err(f, s) < 2e-2, name
         assert rel_err(f, r) < 1.5 * rel_err(s, r) + 2e-3, name   # one rounding fewer, never less accurate
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 768, 768), (8, 2304, 768), (16, 768, 3072), (3, 1024, 256), (5, 50304, 768)])
+@pytest.mark.parametrize("form", ["plain", "ln_bias", "ln_gelu", "bias_residual", "ln_swiglu"])
+def test_decode_linear_forms_match_fp32(B, N, K, form):
+    """The one-launch decode-step linear layer (LayerNorm prologue, bias / GELU / SwiGLU / residual
+    epilogues) against the same chain of stock fp32 ops."""
+    from distributed_pytorch_amd import ops
+    if form == "ln_swiglu" and N > 4096:
+        pytest.skip("no gated head")
+    torch.manual_seed(0)
+    pair = form == "ln_swiglu"
+    x = (torch.randn(B, K, device="cuda") * 1.5 + 0.3).bfloat16()
+    w = (torch.randn(N * (2 if pair else 1), K, device="cuda") / math.sqrt(K)).bfloat16()
+    lw = (torch.randn(K, device="cuda") * 0.2 + 1).bfloat16()
+    lb = (torch.randn(K, device="cuda") * 0.1).bfloat16()
+    bias = (torch.randn(w.shape[0], device="cuda") * 0.2).bfloat16()
+    res = torch.randn(B, N, device="cuda").bfloat16()
+    ln = (lw, lb, 1e-5) if form.startswith("ln") else None
+    b = bias if "bias" in form else None
+    r = res if "residual" in form else None
+    act = {"ln_gelu": ops.ACT_GELU, "ln_swiglu": ops.ACT_SWIGLU}.get(form, ops.ACT_NONE)
+    if ln is not None and K > 2048:
+        assert not ops.decode_linear_supported(x, w, act, True)   # the prologue keeps a row in registers
+        return
+    assert ops.decode_linear_supported(x, w, act, ln is not None)
+    got = ops.decode_linear(x, ln, w, b, r, act)
+    lnf = None if ln is None else (lw.float(), lb.float(), 1e-5)
+    want = ops.decode_linear_eager(x.float(), lnf, w.float(), None if b is None else b.float(),
+                                   None if r is None else r.float(), act)
+    assert got.shape == (B, N) and got.dtype == torch.bfloat16
+    assert rel_err(got, want) < 1e-2
+    assert torch.allclose(got.float(), want, atol=4e-2, rtol=3e-2)
+
+
+def test_decode_linear_writes_new_key_value_rows_into_the_cache():
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    B, S, nh, nkv, hs, K = 4, 32, 8, 2, 64, 512
+    W = (nh + 2 * nkv) * hs
+    x = torch.randn(B, K, device="cuda").bfloat16()
+    w = (torch.randn(W, K, device="cuda") / math.sqrt(K)).bfloat16()
+    bias = (torch.randn(W, device="cuda") * 0.1).bfloat16()
+    kc = torch.randn(B, S, nkv, hs, device="cuda").bfloat16()
+    vc = torch.randn(B, S, nkv, hs, device="cuda").bfloat16()
+    k0, v0 = kc.clone(), vc.clone()
+    pos = torch.tensor([7], dtype=torch.int64, device="cuda")
+    full = ops.decode_linear(x, None, w, bias)
+    q = ops.decode_linear(x, None, w, bias, kv=(kc, vc, pos, nh * hs))
+    assert q.shape == (B, nh * hs) and torch.equal(q, full[:, : nh * hs])
+    assert torch.equal(kc[:, 7].reshape(B, -1), full[:, nh * hs: (nh + nkv) * hs])
+    assert torch.equal(vc[:, 7].reshape(B, -1), full[:, (nh + nkv) * hs:])
+    keep = torch.ones(S, dtype=torch.bool, device="cuda")
+    keep[7] = False
+    assert torch.equal(kc[:, keep], k0[:, keep]) and torch.equal(vc[:, keep], v0[:, keep])   # nothing else is touched
+
+
+def test_sampler_step_form_records_the_token_and_advances_the_counters():
+    """The decode-step form of the sampler: tokens into the next input and the history column, device counters
+    advanced once per launch by the last workgroup, top-1 equal to argmax, draws that change with the position."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    B, V, steps = 6, 50304, 5
+    logits = torch.randn(B, V, device="cuda").bfloat16()
+    seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    tok = torch.zeros(B, 1, dtype=torch.int64, device="cuda")
+    hist = torch.full((B, steps), -1, dtype=torch.int64, device="cuda")
+    hpos = torch.tensor([1], dtype=torch.int64, device="cuda")
+    pos = torch.tensor([17], dtype=torch.int64, device="cuda")
+    fill = torch.tensor([18], dtype=torch.int32, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert ops.sample_step_supported(logits)
+    ops.sample_step(logits, 1.0, 1, seed, tok, hist, hpos, pos, fill, ticket)
+    assert torch.equal(tok[:, 0], logits.float().argmax(-1))
+    assert torch.equal(hist[:, 1], tok[:, 0]) and int((hist >= 0).sum()) == B
+    assert (hpos.item(), pos.item(), fill.item(), ticket.item()) == (2, 18, 19, 0)
+    draws = []
+    for _ in range(3):                                   # same logits, same seed: the position changes the draw
+        ops.sample_step(logits, 1.0, 0, seed, tok, hist, hpos, pos, fill, ticket)
+        draws.append(tok.clone())
+    assert (hpos.item(), pos.item(), fill.item(), ticket.item()) == (5, 21, 22, 0)
+    assert torch.equal(hist[:, 4], draws[2][:, 0])
+    assert not torch.equal(draws[0], draws[1]) and not torch.equal(draws[1], draws[2])
