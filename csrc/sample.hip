@@ -2,9 +2,10 @@
 // draw per row. One workgroup of 1024 threads per row; the row (V <= 57344 logits) is loaded once with
 // coalesced 16-byte accesses and stays in registers (packed bf16) for all the passes:
 //   1. row maximum;
-//   2. the k-th largest logit by a bitwise search on the order-preserving integer image of the floats
-//      (one count-and-reduce per significant bit: 16 for bf16 logits, 32 for fp32), which gives the same
-//      keep set as `logits < topk(logits, k).values[:, -1]` masking, ties included;
+//   2. the k-th largest logit by a bitwise search on the order-preserving integer image of the floats, which
+//      gives the same keep set as `logits < topk(logits, k).values[:, -1]` masking, ties included. For
+//      k <= 512 the search runs over the few logits above a lower bound (the k-th largest of the threads' own
+//      maxima), two bits per round; otherwise over the whole row, one count-and-reduce per significant bit;
 //   3. per-thread partial sums of exp((x - max) / T) over the kept logits, a scan over the threads, and a
 //      walk of the one thread's registers in which u * total falls (u uniform in [0, 1) from a hash of the
 //      seed and the row). The order of the walk is a fixed permutation of the vocabulary, which a
@@ -51,6 +52,39 @@ __device__ __forceinline__ int block_count(int v, int* red) {
   return r;
 }
 
+// Sum of a 64-bit word over the workgroup (every thread gets the result). `red` holds 16 words of LDS.
+__device__ __forceinline__ unsigned long long block_sum64(unsigned long long v, unsigned long long* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  unsigned long long r = 0;
+#pragma unroll
+  for (int i = 0; i < kSampleThreads / 64; ++i) r += red[i];
+  return r;
+}
+
+// Largest key such that at least `topk` of the keys the threads hold (two each; key 0 = none) are >= it, two bits
+// per round: the three candidate prefixes of a round are counted together in 21-bit fields of one word.
+__device__ __forceinline__ unsigned search_kth_key(unsigned k0, unsigned k1, int topk, int low_bit,
+                                                   unsigned long long* red) {
+  unsigned prefix = 0u;
+  for (int bit = 30; bit >= low_bit; bit -= 2) {
+    const unsigned c1 = prefix | (1u << bit), c2 = prefix | (2u << bit), c3 = prefix | (3u << bit);
+    unsigned long long v = (unsigned long long)((k0 >= c1) + (k1 >= c1)) |
+                           ((unsigned long long)((k0 >= c2) + (k1 >= c2)) << 21) |
+                           ((unsigned long long)((k0 >= c3) + (k1 >= c3)) << 42);
+    v = block_sum64(v, red);
+    const int n1 = (int)(v & 0x1FFFFFu), n2 = (int)((v >> 21) & 0x1FFFFFu), n3 = (int)(v >> 42);
+    prefix = n3 >= topk ? c3 : (n2 >= topk ? c2 : (n1 >= topk ? c1 : prefix));
+  }
+  return prefix;
+}
+
+constexpr int kSampleCand = 2048;   // capacity of the candidate list of the top-k search (two per thread)
+
 template <typename T>
 __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __restrict__ logits, long long ld, int V,
                                                                     float inv_temp, int topk,
@@ -79,14 +113,50 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __
       for (int j = 0; j < 8; ++j) mx = fmaxf(mx, e[j]);
     }
   }
+  const float tmax = mx;   // this thread's own maximum
   mx = block_max(mx, red);
 
   unsigned thr_key = 0u;   // keep everything
-  if (topk > 0 && topk < V) {
+  bool found = false;
+  constexpr int kLow = sizeof(T) == 2 ? 16 : 0;   // bf16 images have no low 16 bits
+  if (topk > 0 && topk < V && topk <= kSampleThreads / 2) {
+    // Counting all 56 logits of every thread once per bit is bound by vector instructions on the row's one
+    // workgroup. The topk-th largest of the THREAD MAXIMA is a lower bound of the topk-th largest logit (those
+    // maxima are topk different logits), and few logits lie above it: they are gathered in LDS and the search
+    // runs over them alone. For a candidate prefix below the bound every count is >= topk either way, above it
+    // the counts over the list are the counts over the row, so the result is the same key.
+    __shared__ unsigned long long red64[16];
+    __shared__ unsigned cand[kSampleCand];
+    __shared__ int ncand;
+    if (tid == 0) ncand = 0;
+    const unsigned bound = search_kth_key(tid < nvec ? order_key(tmax) : 0u, 0u, topk, kLow, red64);
+#pragma unroll
+    for (int k = 0; k < kSampleVecs; ++k) {
+      if (tid + k * kSampleThreads < nvec) {
+        float e[8];
+        v[k].get(e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned key = order_key(e[j]);
+          if (key >= bound) {
+            const int at = atomicAdd(&ncand, 1);
+            if (at < kSampleCand) cand[at] = key;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int n = ncand;
+    if (n <= kSampleCand) {
+      thr_key = search_kth_key(tid < n ? cand[tid] : 0u, tid + kSampleThreads < n ? cand[tid + kSampleThreads] : 0u, topk,
+                               kLow, red64);
+      found = true;
+    }
+  }
+  if (topk > 0 && topk < V && !found) {
     // largest key such that at least `topk` logits are >= it: the key of the k-th largest logit
-    constexpr int kLowBit = sizeof(T) == 2 ? 16 : 0;   // bf16 images have no low 16 bits
     unsigned prefix = 0u;
-    for (int bit = 31; bit >= kLowBit; --bit) {
+    for (int bit = 31; bit >= kLow; --bit) {
       const unsigned cand = prefix | (1u << bit);
       int cnt = 0;
 #pragma unroll
