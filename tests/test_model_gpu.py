@@ -226,3 +226,21 @@ def test_graphed_decode_matches_eager_decode(name):
     assert agree > 0.97, agree            # identical kernels and maths; a bf16 near-tie may flip an argmax
     sampled = model.generate(idx, 40, temperature=0.8, topk=50)       # default: graphed, real sampling
     assert sampled.shape == (3, 57) and int(sampled.max()) < cfg.vocab_size
+
+
+@pytest.mark.parametrize("batch", [1, 16, 17])
+def test_graphed_decode_batch_sizes_around_the_fused_kernels_limit(batch):
+    """The captured decode step on the one-launch decode layers (up to 16 sequences) and on the stock launches
+    (17: beyond the kernels' rows) produces the eager cache path's tokens."""
+    torch.manual_seed(0)
+    cfg = LLMconfig(**{**BASE, **VARIANTS["gpt2"]}).finalize()
+    model = LLM(cfg).to("cuda").to(torch.bfloat16)
+    model.eval()
+    idx = torch.randint(0, cfg.vocab_size, (batch, 9), device="cuda")
+    eager = model.generate(idx, 24, temperature=1.0, topk=1, hip_graph=False)
+    graphed = model.generate(idx, 24, temperature=1.0, topk=1, hip_graph=True)
+    assert model.last_decode_graphed
+    assert graphed.shape == eager.shape == (batch, 33)
+    assert (graphed == eager).float().mean().item() > 0.97
+    x = torch.randn(batch, 1, cfg.n_embd, device="cuda").bfloat16()
+    assert model.transformer.h[0]._decode_ok(x) == (batch <= 16)
