@@ -472,6 +472,40 @@ std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tens
   return {o, lse};
 }
 
+// One new token per sequence over a preallocated cache: q [B, 1, nh, hs], caches [B, S, nkv, hs], kv_len int32 [1]
+// on the device (csrc/attn_decode.hip).
+Tensor attn_decode(const Tensor& q, const Tensor& k, const Tensor& v, double scale, const Tensor& kv_len) {
+  const int64_t hs = q.size(3);
+  TORCH_CHECK(q.dim() == 4 && q.size(1) == 1 && (hs == 64 || hs == 128), "attn_decode: q is [B, 1, nh, 64 | 128]");
+  check_heads(q, "q", hs);
+  check_heads(k, "k", hs);
+  check_heads(v, "v", hs);
+  TORCH_CHECK(k.size(0) == q.size(0) && v.sizes() == k.sizes() && q.size(2) % k.size(2) == 0, "attn_decode: shape mismatch");
+  TORCH_CHECK(kv_len.is_cuda() && kv_len.scalar_type() == at::kInt && kv_len.numel() == 1,
+              "attn_decode: kv_len must be a one-element int32 tensor on the GPU");
+  Tensor o = at::empty({q.size(0), 1, q.size(2), hs}, q.options());
+  dpa::AttnDecodeArgs p{};
+  p.q = q.data_ptr();
+  p.k = k.data_ptr();
+  p.v = v.data_ptr();
+  p.o = o.data_ptr();
+  p.q_bs = q.stride(0);
+  p.o_bs = o.stride(0);
+  p.k_bs = k.stride(0);
+  p.v_bs = v.stride(0);
+  p.k_ts = (int)k.stride(1);
+  p.v_ts = (int)v.stride(1);
+  p.B = (int)q.size(0);
+  p.nh = (int)q.size(2);
+  p.nkv = (int)k.size(2);
+  p.hs = (int)hs;
+  p.S = (int)k.size(1);
+  p.scale = (float)scale;
+  p.kv_len = kv_len.data_ptr<int>();
+  dpa::attn_decode(p, cur_stream());
+  return o;
+}
+
 // fp32 [positions, hs / 2] cos / sin tables on the GPU covering positions [0, need)
 void check_rope_tables(const Tensor& c, const Tensor& s, int64_t hs, int64_t need, const char* who) {
   TORCH_CHECK(c.is_cuda() && s.is_cuda() && c.scalar_type() == at::kFloat && s.scalar_type() == at::kFloat &&
@@ -1205,6 +1239,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("swiglu_fwd(Tensor h) -> Tensor");
   m.def("swiglu_bwd(Tensor dy, Tensor h) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? kv_len=None) -> (Tensor, Tensor)");
+  m.def("attn_decode(Tensor q, Tensor k, Tensor v, float scale, Tensor kv_len) -> Tensor");
   m.def("attn_dropout_mask(int B, int nh, int Tq, int Tk, float p_drop, Tensor seed) -> Tensor");
   m.def("attn_bwd(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor(a!) dq, Tensor(b!) dk, "
         "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? rope_cos=None, Tensor? rope_sin=None, "
@@ -1273,5 +1308,6 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("attn_fwd", attn_fwd);
   m.impl("attn_dropout_mask", attn_dropout_mask);
   m.impl("attn_bwd", attn_bwd);
+  m.impl("attn_decode", attn_decode);
   m.impl("rope_", rope_);
 }

@@ -89,6 +89,19 @@ void attn_bwd(const AttnParams& p, hipStream_t st);
 void attn_dropout_mask(unsigned char* keep, int B, int nh, int Tq, int Tk, float p_drop, const long long* seed,
                        hipStream_t st);
 
+// Single-query attention over a KV cache (csrc/attn_decode.hip): q, o [B, 1, nh, hs] (batch strides q_bs / o_bs,
+// heads packed), k, v [B, S, nkv, hs] (strides *_bs, *_ts), *kv_len valid keys (clamped to S), hs 64 or 128.
+struct AttnDecodeArgs {
+  const void *q, *k, *v;
+  void* o;
+  long long q_bs, o_bs, k_bs, v_bs;
+  int k_ts, v_ts;
+  int B, nh, nkv, hs, S;
+  float scale;
+  const int* kv_len;
+};
+void attn_decode(const AttnDecodeArgs& p, hipStream_t st);
+
 // ---- Weight-gradient GEMM -----------------------------------------------------------------
 // ws[N, K] (fp32) += dy[M, N]^T * x[M, K]; dbias[N] (fp32, optional) += column sums of dy.
 // N and K must be multiples of 128; rows 16-byte aligned. With splits > 1 the token range is

@@ -19,6 +19,7 @@ reproduce.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -248,6 +249,10 @@ def cached_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     if _hip_ok(q, k_cache, v_cache):
+        if (q.shape[1] == 1 and q.shape[2] % k_cache.shape[2] == 0 and hasattr(ops(), "attn_decode")
+                and os.environ.get("DPA_FUSED_DECODE", "1") != "0"):
+            # one query per sequence: the keys are divided over the waves instead of the queries
+            return ops().attn_decode(_packed(q), k_cache, v_cache, float(scale), kv_len)
         o, _ = ops().attn_fwd(_packed(q), k_cache, v_cache, float(scale), 0.0, None, kv_len)
         return o
     n = int(kv_len.item())

@@ -669,7 +669,7 @@ def test_activation_map_kernels(name, dtype):
     assert rel_err(y, yr) < tol and rel_err(x.grad, xr.grad) < tol
 
 
-@pytest.mark.parametrize("nh,nkv,hs", [(4, 4, 64), (8, 2, 128)])
+@pytest.mark.parametrize("nh,nkv,hs", [(4, 4, 64), (8, 2, 128), (12, 4, 64), (12, 1, 64), (6, 3, 128)])
 def test_cached_attention_reads_the_fill_level_from_the_device(nh, nkv, hs):
     """Decode attention over a preallocated cache: the number of valid keys is a device scalar, stale
     rows beyond it are never read, and changing the scalar changes the result without a new launch shape."""
