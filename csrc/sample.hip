@@ -5,7 +5,8 @@
 //   2. the k-th largest logit by a bitwise search on the order-preserving integer image of the floats, which
 //      gives the same keep set as `logits < topk(logits, k).values[:, -1]` masking, ties included. For
 //      k <= 512 the search runs over the few logits above a lower bound (the k-th largest of the threads' own
-//      maxima), two bits per round; otherwise over the whole row, one count-and-reduce per significant bit;
+//      maxima), two bits per round, by one wave without workgroup barriers; otherwise over the whole row, one
+//      count-and-reduce per significant bit;
 //   3. per-thread partial sums of exp((x - max) / T) over the kept logits, a scan over the threads, and a
 //      walk of the one thread's registers in which u * total falls (u uniform in [0, 1) from a hash of the
 //      seed and the row). The order of the walk is a fixed permutation of the vocabulary, which a
@@ -52,33 +53,39 @@ __device__ __forceinline__ int block_count(int v, int* red) {
   return r;
 }
 
-// Sum of a 64-bit word over the workgroup (every thread gets the result). `red` holds 16 words of LDS.
-__device__ __forceinline__ unsigned long long block_sum64(unsigned long long v, unsigned long long* red) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wid] = v;
-  __syncthreads();
-  unsigned long long r = 0;
-#pragma unroll
-  for (int i = 0; i < kSampleThreads / 64; ++i) r += red[i];
-  return r;
+// Sum of an unsigned over the wave: four rotations inside each row of 16 lanes (DPP), two exchanges between rows.
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);
+  v += (unsigned)__shfl_xor((int)v, 16, 64);
+  v += (unsigned)__shfl_xor((int)v, 32, 64);
+  return v;
 }
 
-// Largest key such that at least `topk` of the keys the threads hold (two each; key 0 = none) are >= it, two bits
-// per round: the three candidate prefixes of a round are counted together in 21-bit fields of one word.
-__device__ __forceinline__ unsigned search_kth_key(unsigned k0, unsigned k1, int topk, int low_bit,
-                                                   unsigned long long* red) {
+// By ONE wave: the largest key such that at least `topk` of keys[0 .. n) (LDS, n <= 2048, key 0 = none) are >= it.
+// Two bits per round, the three candidate prefixes of a round counted together; the lane's keys stay in registers
+// and the rounds need no workgroup barrier (a round over the whole workgroup costs about a microsecond of barriers).
+__device__ __forceinline__ unsigned wave_search_kth_key(const unsigned* keys, int n, int topk, int low_bit, int lane) {
+  unsigned k[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) k[i] = (lane + 64 * i) < n ? keys[lane + 64 * i] : 0u;
+  const int used = (n + 63) >> 6;
   unsigned prefix = 0u;
   for (int bit = 30; bit >= low_bit; bit -= 2) {
     const unsigned c1 = prefix | (1u << bit), c2 = prefix | (2u << bit), c3 = prefix | (3u << bit);
-    unsigned long long v = (unsigned long long)((k0 >= c1) + (k1 >= c1)) |
-                           ((unsigned long long)((k0 >= c2) + (k1 >= c2)) << 21) |
-                           ((unsigned long long)((k0 >= c3) + (k1 >= c3)) << 42);
-    v = block_sum64(v, red);
-    const int n1 = (int)(v & 0x1FFFFFu), n2 = (int)((v >> 21) & 0x1FFFFFu), n3 = (int)(v >> 42);
-    prefix = n3 >= topk ? c3 : (n2 >= topk ? c2 : (n1 >= topk ? c1 : prefix));
+    unsigned n12 = 0u, n3 = 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i < used) {
+        n12 += (k[i] >= c1 ? 1u : 0u) + (k[i] >= c2 ? 0x10000u : 0u);
+        n3 += k[i] >= c3 ? 1u : 0u;
+      }
+    n12 = wave_sum_u32(n12);
+    n3 = wave_sum_u32(n3);
+    const int n1 = (int)(n12 & 0xFFFFu), n2 = (int)(n12 >> 16);
+    prefix = (int)n3 >= topk ? c3 : (n2 >= topk ? c2 : (n1 >= topk ? c1 : prefix));
   }
   return prefix;
 }
@@ -125,11 +132,19 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __
     // maxima are topk different logits), and few logits lie above it: they are gathered in LDS and the search
     // runs over them alone. For a candidate prefix below the bound every count is >= topk either way, above it
     // the counts over the list are the counts over the row, so the result is the same key.
-    __shared__ unsigned long long red64[16];
+    __shared__ unsigned tkeys[kSampleThreads];
     __shared__ unsigned cand[kSampleCand];
     __shared__ int ncand;
+    __shared__ unsigned found_key;
+    tkeys[tid] = tid < nvec ? order_key(tmax) : 0u;
     if (tid == 0) ncand = 0;
-    const unsigned bound = search_kth_key(tid < nvec ? order_key(tmax) : 0u, 0u, topk, kLow, red64);
+    __syncthreads();
+    if (wid == 0) {
+      const unsigned bnd = wave_search_kth_key(tkeys, kSampleThreads, topk, kLow, lane);
+      if (lane == 0) found_key = bnd;
+    }
+    __syncthreads();
+    const unsigned bound = found_key;
 #pragma unroll
     for (int k = 0; k < kSampleVecs; ++k) {
       if (tid + k * kSampleThreads < nvec) {
@@ -148,8 +163,12 @@ __global__ __launch_bounds__(kSampleThreads) void sample_topk_kernel(const T* __
     __syncthreads();
     const int n = ncand;
     if (n <= kSampleCand) {
-      thr_key = search_kth_key(tid < n ? cand[tid] : 0u, tid + kSampleThreads < n ? cand[tid + kSampleThreads] : 0u, topk,
-                               kLow, red64);
+      if (wid == 0) {
+        const unsigned key = wave_search_kth_key(cand, n, topk, kLow, lane);
+        if (lane == 0) found_key = key;
+      }
+      __syncthreads();
+      thr_key = found_key;
       found = true;
     }
   }
