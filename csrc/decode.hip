@@ -11,7 +11,7 @@
 // straight into the preallocated KV cache at the device-side position, so a dense block is five launches.
 //
 // Structure: one 256-thread workgroup per 16 output features. The activations sit in LDS as bf16 (rows
-// padded by 16 bytes), zero rows past B. v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as the row operand:
+// padded by 16 bytes; only the B real rows, so 8 rows of width 8192 still fit). v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as the row operand:
 // a lane's 16-byte global load of W[n0 + lane % 16][k0 + 8 (lane / 16) ..] is exactly its fragment, no LDS
 // and no cross-lane reduction for the weights; the activation fragment is one ds_read_b128. The four waves
 // split K, their partial 16 x 16 tiles are added through LDS by wave 0, which applies the epilogue and
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = p.K, B = p.B;
   const int xstride = K * 2 + 16;                        // bytes per staged row
-  float* part = reinterpret_cast<float*>(smem + 16 * xstride);   // [pair][wave][lane][4]
+  float* part = reinterpret_cast<float*>(smem + B * xstride);    // [pair][wave][lane][4]
   const bf16_t* x = reinterpret_cast<const bf16_t*>(p.x);
 
   // ---- weight fragments of this wave's quarter of K (pairs: 16 gate + the 16 matching up rows) ----
@@ -87,13 +87,12 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
       rr = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.residual) + (long long)l15 * p.ldr + n);
   }
 
-  // ---- stage the activations: LayerNorm (fp32 statistics, two passes over registers) or a copy; zero rows past B ----
+  // ---- stage the activations: LayerNorm (fp32 statistics, two passes over registers) or a copy (rows past B are not staged) ----
   if constexpr (!LN) {
-    for (int b = wave; b < 16; b += NW) {
+    for (int b = wave; b < B; b += NW) {
       char* row = smem + b * xstride;
       const bf16_t* xr = x + (long long)b * p.ldx;
-      for (int k = lane * 8; k < K; k += 512)
-        *reinterpret_cast<u32x4*>(row + k * 2) = b < B ? *reinterpret_cast<const u32x4*>(xr + k) : u32x4{0u, 0u, 0u, 0u};
+      for (int k = lane * 8; k < K; k += 512) *reinterpret_cast<u32x4*>(row + k * 2) = *reinterpret_cast<const u32x4*>(xr + k);
     }
   } else {
     // the wave's rows b = wave + 4 i together: their loads and their reductions overlap
@@ -150,14 +149,12 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
 #pragma unroll
       for (int j = 0; j < kLnVec; ++j) {
         const int k = lane * 8 + 512 * j;
-        if (k < K) {
-          u32x4 o = {0u, 0u, 0u, 0u};
-          if (b < B) {
+        if (k < K && b < B) {
+          u32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o[e] = pack_bf16x2((lo_bf16(xv[i][j][e]) - mean[i]) * rstd[i] * lo_bf16(gv[j][e]) + lo_bf16(bv[j][e]),
-                                 (hi_bf16(xv[i][j][e]) - mean[i]) * rstd[i] * hi_bf16(gv[j][e]) + hi_bf16(bv[j][e]));
-          }
+          for (int e = 0; e < 4; ++e)
+            o[e] = pack_bf16x2((lo_bf16(xv[i][j][e]) - mean[i]) * rstd[i] * lo_bf16(gv[j][e]) + lo_bf16(bv[j][e]),
+                               (hi_bf16(xv[i][j][e]) - mean[i]) * rstd[i] * hi_bf16(gv[j][e]) + hi_bf16(bv[j][e]));
           *reinterpret_cast<u32x4*>(row + k * 2) = o;
         }
       }
@@ -166,7 +163,8 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
   __syncthreads();
 
   // ---- products: fragments in batches of 8, the next batch requested ahead of the current one's MFMAs ----
-  const char* xfrag = smem + l15 * xstride + (kbeg + 8 * g) * 2;
+  // only the B real rows are staged: the MFMA's columns past B read row B - 1 again and are never stored
+  const char* xfrag = smem + (l15 < B ? l15 : B - 1) * xstride + (kbeg + 8 * g) * 2;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   for (int base = 0; base < nf; base += 8) {
     dfrag8 an[8] = {}, an2[8] = {};
@@ -244,7 +242,7 @@ static bool wide_split(const DecodeLinearArgs& p) {
 }
 
 bool decode_linear_ok(long long B, long long N, long long K, long long ldx, long long ldw, bool pair, bool has_ln) {
-  const long long lds = 16 * (K * 2 + 16) + (pair ? 2 : 1) * 16384;
+  const long long lds = B * (K * 2 + 16) + (pair ? 2 : 1) * 16384;   // the staged rows + the waves' partial tiles
   if (has_ln && K > 512 * kLnVec) return false;   // the LayerNorm prologue keeps a row in registers
   return B >= 1 && B <= 16 && N >= 16 && N % 16 == 0 && K >= 128 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
          lds <= 160 * 1024;
@@ -252,7 +250,7 @@ bool decode_linear_ok(long long B, long long N, long long K, long long ldx, long
 
 template <int ACT, int NW, bool LN>
 static void launch(const DecodeLinearArgs& p, hipStream_t st) {
-  const size_t lds = 16 * ((size_t)p.K * 2 + 16) + (ACT == kDecodeSwiglu ? 2 : 1) * NW * 1024;
+  const size_t lds = (size_t)p.B * ((size_t)p.K * 2 + 16) + (ACT == kDecodeSwiglu ? 2 : 1) * NW * 1024;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)decode_linear_kernel<ACT, NW, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,

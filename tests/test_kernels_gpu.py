@@ -1095,7 +1095,8 @@ def test_qkv_rope_attention_fused_matches_separate_passes(nh, nkv, hs):
         assert rel_err(f, r) < 1.5 * rel_err(s, r) + 2e-3, name   # one rounding fewer, never less accurate
 
 
-@pytest.mark.parametrize("B,N,K", [(1, 768, 768), (8, 2304, 768), (16, 768, 3072), (3, 1024, 256), (5, 50304, 768)])
+@pytest.mark.parametrize("B,N,K", [(1, 768, 768), (8, 2304, 768), (16, 768, 3072), (3, 1024, 256), (5, 50304, 768),
+                                   (8, 2048, 8192), (7, 8192, 2048)])
 @pytest.mark.parametrize("form", ["plain", "ln_bias", "ln_gelu", "bias_residual", "ln_swiglu"])
 def test_decode_linear_forms_match_fp32(B, N, K, form):
     """The one-launch decode-step linear layer (LayerNorm prologue, bias / GELU / SwiGLU / residual
