@@ -33,11 +33,11 @@ from distributed_pytorch_amd.utils.metrics import PEAK_BF16_DENSE_FLOPS, mfu, mo
 # tokens/s per GPU of the reference's own single-GPU trainer loop (eager PyTorch, bf16 autocast, fused
 # AdamW, no torch.compile: there is no Triton on this image) for GPT-2-124M at T = 1024 on one MI355X,
 # measured with benchmarks/reference_baseline.py, keyed by micro-batch. `vs_baseline` uses the
-# reference's BEST micro-batch: the reference gains nothing from a larger one (its loop is launch- and
-# elementwise-bound), so this is the strongest denominator available.
-REFERENCE_TOKENS_PER_S_PER_GPU = {16: 409_953.0, 32: 446_660.0}
+# reference's BEST micro-batch (it keeps gaining up to 256 sequences, 207 GB), which is also this
+# benchmark's default micro-batch: the strongest denominator available.
+REFERENCE_TOKENS_PER_S_PER_GPU = {16: 409_953.0, 32: 449_428.0, 64: 485_364.0, 128: 502_596.0, 256: 516_934.0}
 BASELINE_SOURCE = ("self-measured reference loop (reference model + its trainer loop, bf16 autocast, fused AdamW, "
-                   "no torch.compile), best of micro-batch 16 / 32, benchmarks/reference_baseline.py")
+                   "no torch.compile), best of micro-batch 16 ... 256, benchmarks/reference_baseline.py")
 
 
 def main():
