@@ -182,7 +182,6 @@ def qkv_rope_attention_supported(x: torch.Tensor, w: torch.Tensor, b, cos_t: tor
     """Shapes the fused projection + rotary + attention path takes: bf16 on the GPU, head size 64 or 128,
     sequences of a multiple of 128 tokens (a 128-row block of the GEMM's output tile must not straddle two
     sequences), tables that cover the positions (and row 16, the step of the epilogue's angle addition)."""
-    import os
     from .linear import gemm_supported
     if not (use_hip(x, w, cos_t, sin_t) and x.dim() == 3 and x.dtype == torch.bfloat16 and hs in (64, 128)):
         return False
