@@ -224,6 +224,29 @@ __device__ __forceinline__ bfrag scaled_frag(const bf16_t* src, float c) {
 // least sum the first tile must reach for the initial reference (0) to be kept.
 constexpr float kSumHi = 1.0e9f, kSumLo = 1.0e-9f;
 
+// Timing-only ablations of the forward at head size 64 (benchmarks/ab_build.py ... -DDPA_ATTN_ABLATE=n, wrong
+// results): 1 = no exponential and never a redo, 2 = additionally no P V products. Measured at B64 T1024: 173.1 us
+// -> 170.3 (1) -> 138.9 (2): the exponentials are already hidden, a product is not.
+#ifndef DPA_ATTN_ABLATE
+#define DPA_ATTN_ABLATE 0
+#endif
+__device__ __forceinline__ float fwd_exp2(float x) { return DPA_ATTN_ABLATE ? x : __builtin_amdgcn_exp2f(x); }
+
+// Timing trace of the forward (benchmark builds with -DDPA_ATTN_TRACE only): the four waves of one workgroup stamp
+// the shader clock at seven points of each of their first 16 key tiles into LDS; at the end the low words replace
+// the first 448 log-sum-exp outputs of (batch 0, head 0), where the benchmark script reads them.
+#ifdef DPA_ATTN_TRACE
+#define DPA_ATR(slot)                                                                                       \
+  do {                                                                                                      \
+    if (tracing && t < 16) {                                                                                \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+      if (lane == 0) trace_s[wave][t][slot] = (unsigned)t_;                                                 \
+    }                                                                                                       \
+  } while (0)
+#else
+#define DPA_ATR(slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Forward
 //
@@ -292,14 +315,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   if (qlim > Tk - 1) qlim = Tk - 1;
   const unsigned dkey = DROP ? drop_key(p.seed, bh) : 0u, dthr = DROP ? drop_threshold(p.p_drop) : 0u;
 
+#ifdef DPA_ATTN_TRACE
+  __shared__ unsigned trace_s[4][16][7];
+  const bool tracing = blockIdx.x == 300 && HS == 64;   // a workgroup of the first batch with all 16 tiles
+  if (tracing) for (int i = tid; i < 4 * 16 * 7; i += 256) (&trace_s[0][0][0])[i] = 0u;
+#endif
   for (int t = 0; t < ntiles; ++t) {
+    DPA_ATR(0);
     wait_dma();
     __syncthreads();   // tile t has landed for every wave; every wave is done with tile t - 1's buffer
+    DPA_ATR(1);
     if (t + 1 < ntiles) {
       const unsigned nb = lds0 + ((t + 1) & 1) * 2 * TILE;
       kd.issue(krs, (t + 1) * 64, Tk, nb);
       vd.issue(vrs, (t + 1) * 64, Tk, nb + TILE);
     }
+    DPA_ATR(2);
     const char* kb = smem + (t & 1) * 2 * TILE;
     const char* vb = kb + TILE;
     const int kv0 = t * 64;
@@ -337,6 +368,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         }
       };
       scores(negm);
+      DPA_ATR(3);
       bfrag vf[KSUB][2][ND];
 #pragma unroll
       for (int u = 0; u < KSUB; ++u)
@@ -350,11 +382,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          s[sub][i] = __builtin_amdgcn_exp2f(s[sub][i]);
+          s[sub][i] = fwd_exp2(s[sub][i]);
           rs += s[sub][i];
         }
+      DPA_ATR(4);
       bool redo = !__all(rs <= kSumHi);
       if (t == 0) redo = redo || !__all(sum_halves(rs) >= kSumLo);
+      if (DPA_ATTN_ABLATE) redo = false;
       if (redo) {
         f32x16 zero;
 #pragma unroll
@@ -412,9 +446,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           for (int s2 = 0; s2 < 2; ++s2) {
             const bfrag pb = acc_frag(s[sb + u], s2);
 #pragma unroll
-            for (int dt = 0; dt < ND; ++dt) oacc[dt] = mfma32(vf[u][s2][dt], pb, oacc[dt]);
+            for (int dt = 0; dt < ND; ++dt) {
+              if (DPA_ATTN_ABLATE == 2) asm volatile("" : "+v"(oacc[dt]) : "v"(vf[u][s2][dt]), "v"(pb));
+              else oacc[dt] = mfma32(vf[u][s2][dt], pb, oacc[dt]);
+            }
           }
       }
+      DPA_ATR(5);
     }
     } else {
     // Wider heads: one sub-tile at a time, which keeps the kernel at two waves per SIMD (+37 % at head size 128).
@@ -514,6 +552,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   __syncthreads();  // all waves are done with the K/V tiles before the region is reused
   bf16_t* op = (bf16_t*)p.o + b * p.o_bs + h * HS;
   store_tile_T<HS>(smem + wave * 32 * HS * 2, oacc, inv, op, p.o_ts, q0 + wave * 32, p.Tq, lane);
+#ifdef DPA_ATTN_TRACE
+  if (tracing) {
+    __syncthreads();
+    for (int i = tid; i < 4 * 16 * 7; i += 256) reinterpret_cast<unsigned*>(p.lse)[i] = (&trace_s[0][0][0])[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
