@@ -19,6 +19,9 @@ class ByteTokenizer:
     def encode_ordinary(self, text: str):
         return list(text.encode("utf-8"))
 
+    def decode(self, ids) -> str:
+        return bytes(i for i in ids if 0 <= i < 256).decode("utf-8", errors="replace")
+
 
 class _HFTokenizer:
     name = "hf-tokenizers-gpt2"
@@ -31,6 +34,9 @@ class _HFTokenizer:
 
     def encode_ordinary(self, text: str):
         return self.tok.encode(text, add_special_tokens=False).ids
+
+    def decode(self, ids) -> str:
+        return self.tok.decode(list(ids))
 
 
 def get_encoder(prefer: str = "gpt2"):

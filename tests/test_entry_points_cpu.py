@@ -1,5 +1,6 @@
 """Every training entry script (the reference's file layout) starts, trains a few steps on the CPU and exits
 cleanly as a single process."""
+import json
 import os
 import subprocess
 import sys
@@ -28,3 +29,22 @@ def test_entry_script_trains(script, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step: 3 ")]
     assert len(steps) == 1 and "train loss" in steps[0], r.stdout[-1500:]
+
+
+def test_sample_script_reads_saved_model(tmp_path):
+    """--save_model writes a checkpoint that single-gpu/sample.py loads and samples from, with no model flags."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    common = [a if a != "256" else "257" for a in COMMON]          # the byte tokeniser's vocabulary
+    cmd = [sys.executable, os.path.join(ROOT, "single-gpu/train.py"), *common, "--data_dir", str(tmp_path / "data"),
+           "--file_name", str(tmp_path / "out"), "--save_model"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = [sys.executable, os.path.join(ROOT, "single-gpu/sample.py"), "--ckpt", str(tmp_path / "out_ckpt.pt"), "--prompt", "To be",
+           "--max_new_tokens", "40", "--num_samples", "2", "--tokenizer", "bytes", "--token_ids", "--device", "cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("[") and not ln.startswith("[sample]")]
+    assert len(rows) == 2 and all(len(x) == 5 + 40 for x in rows), r.stdout[-800:]
+    assert all(x[:5] == list(b"To be") and max(x) < 257 for x in rows)
