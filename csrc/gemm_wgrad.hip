@@ -28,6 +28,12 @@
 
 namespace dpa {
 
+// Timing ablations of wgrad3_kernel (benchmark builds only; results are wrong): 1 = no wait for the LDS-DMA,
+// 2 = no LDS-DMA after the first tile, 3 = LDS-DMA only (no fragment reads, no MFMAs)
+#ifndef DPA_WG3_ABLATE
+#define DPA_WG3_ABLATE 0
+#endif
+
 constexpr int kWgTile = 128;   // output tile edge
 constexpr int kWgStep = 64;    // tokens per LDS tile
 
@@ -302,10 +308,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   for (int t = 0; t < ntiles; ++t) {
     // tile t has landed (this wave's DMAs drained, then everybody's through the barrier); the same
     // barrier proves that every wave is done reading the stage that tile t+1 is about to overwrite
+#if DPA_WG3_ABLATE != 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#if DPA_WG3_ABLATE != 2
     if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+#endif
+#if DPA_WG3_ABLATE == 3
+    continue;
+#endif
     const char* ya = smem + (t & 1) * STAGE + wn * SUB;
     const char* xb = smem + (t & 1) * STAGE + (2 + wk) * SUB;
 #pragma unroll
