@@ -1024,6 +1024,7 @@ Tensor gemm_nt_rope(const Tensor& a, const Tensor& b, const std::optional<Tensor
   g.rope_hs = (int)hs;
   g.rope_T = (int)seq_len;
   g.rope_pos0 = (int)pos0;
+  TORCH_CHECK(dpa::gemm_nt_rows_per_launch(g, dpa::kEpiRope) > 0, "gemm_nt_rope: rows too wide for one aligned row range");
   dpa::gemm_nt(g, dpa::kEpiRope, gemm_cus(), cur_stream());
   return c;
 }
@@ -1129,6 +1130,8 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const
   }
   TORCH_CHECK(dpa::gemm_nt_ok(rows, N, K, a.stride(0), ldw, N, ld_aux, false), "gemm_nt_grouped: unsupported shape ", rows,
               "x", N, "x", K);
+  TORCH_CHECK(rows * std::max<int64_t>(std::max<int64_t>(a.stride(0), N), ld_aux) * 2 < (int64_t(1) << 31),
+              "gemm_nt_grouped: the row-indexed operands must stay below 2 GiB (the grouped form is one launch)");
   Tensor c = at::empty({rows, N}, a.options());
   std::optional<Tensor> aux_out;
   dpa::GemmNtArgs g{};

@@ -885,8 +885,37 @@ bool gemm_nt_pair_ok(long long M, long long N, long long K, long long lda, long 
 int g_gemm_nt_variant = 0;   // benchmark knob: bit 0 = one barrier per phase, bit 1 = drop the stores (timing only)
 void gemm_nt_set_variant(int v) { g_gemm_nt_variant = v; }
 
+long long gemm_nt_rows_per_launch(const GemmNtArgs& a, int epi) {
+  if (a.w_ptrs != nullptr) return a.M;      // grouped mode indexes its weight table by absolute row block
+  long long ldm = a.lda > a.ldc ? a.lda : a.ldc;
+  if ((a.aux_in != nullptr || a.aux_out != nullptr) && a.ld_aux > ldm) ldm = a.ld_aux;
+  long long align = 256;
+  if (epi == kEpiRope && a.rope_T > 0) align = a.rope_T % 256 == 0 ? a.rope_T : 2ll * a.rope_T;   // rope_T % 128 == 0
+  return gemm_nt_row_chunk(a.M, ldm, align);
+}
+
+static void gemm_nt_launch(GemmNtArgs a, int epi, int num_cus, hipStream_t st);
+
 void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   if (a.M == 0 || a.N == 0) return;
+  const long long chunk = gemm_nt_rows_per_launch(a, epi);
+  if (chunk <= 0) {
+    fprintf(stderr, "gemm_nt: a row range of the operands does not fit 2 GiB (callers check gemm_nt_rows_per_launch)\n");
+    abort();
+  }
+  const int M = a.M;
+  for (long long m0 = 0; m0 < M; m0 += chunk) {
+    GemmNtArgs s = a;
+    s.M = (int)(M - m0 < chunk ? M - m0 : chunk);
+    s.a = static_cast<const char*>(a.a) + m0 * a.lda * 2;
+    s.c = static_cast<char*>(a.c) + m0 * a.ldc * 2;
+    if (a.aux_in != nullptr) s.aux_in = static_cast<const char*>(a.aux_in) + m0 * a.ld_aux * 2;
+    if (a.aux_out != nullptr) s.aux_out = static_cast<char*>(a.aux_out) + m0 * a.ld_aux * 2;
+    gemm_nt_launch(s, epi, num_cus, st);
+  }
+}
+
+static void gemm_nt_launch(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
   a.tiles_m = (a.M + 255) / 256;
   const long long b_rows = epi == kEpiSwiglu ? 2ll * a.N : a.N;           // weight rows
   const long long c_cols = epi == kEpiDswiglu ? 2ll * a.N : a.N;          // columns of c

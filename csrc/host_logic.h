@@ -70,8 +70,18 @@ inline int gemm_nt_grid(int tiles_m, int tiles_n, int num_cus) {
   return grid;
 }
 
-// Shapes the NT GEMM accepts. Every byte offset the kernel forms must stay below 2 GiB: offsets at or
-// above that are its "outside every buffer" range, used to turn loads into zeros and stores into no-ops.
+// Rows of one launch of the NT GEMM. Every byte offset the kernel forms must stay below 2 GiB: offsets at or
+// above that are its "outside every buffer" range, used to turn loads into zeros and stores into no-ops. The
+// rows of an NT product are independent, so a taller problem runs as several launches over row ranges of at
+// most this many rows (a multiple of `align`; 0 if not even `align` rows fit). `ld_max` is the widest row
+// stride (in elements) among the row-indexed operands.
+inline long long gemm_nt_row_chunk(long long M, long long ld_max, long long align) {
+  const long long lim = 0x80000000ll;
+  if (M * ld_max * 2 < lim) return M;
+  return (lim - 1) / (ld_max * 2) / align * align;
+}
+
+// Shapes the NT GEMM accepts (any number of rows: see gemm_nt_row_chunk).
 inline bool gemm_nt_shape_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc,
                              long long ld_aux, bool has_bias) {
   const long long lim = 0x80000000ll;
@@ -79,7 +89,12 @@ inline bool gemm_nt_shape_ok(long long M, long long N, long long K, long long ld
   if (lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ld_aux % 8 != 0) return false;
   if (lda < K || ldb < K || ldc < N || (ld_aux != 0 && ld_aux < N)) return false;
   if (M >= lim || N >= lim || lda >= lim || ldb >= lim || ldc >= lim || ld_aux >= lim) return false;
-  if (M * lda * 2 >= lim || N * ldb * 2 >= lim || M * ldc * 2 >= lim || M * ld_aux * 2 >= lim) return false;
+  if (N * ldb * 2 >= lim) return false;
+  {
+    long long ldm = lda > ldc ? lda : ldc;
+    if (ld_aux > ldm) ldm = ld_aux;
+    if (gemm_nt_row_chunk(M, ldm, 256) < 256 && M * ldm * 2 >= lim) return false;
+  }
   if (256 * lda * 2 >= (1ll << 30) || 256 * ldb * 2 >= (1ll << 30)) return false;
   if (has_bias && N > kGemmNtMaxBiasN) return false;
   return true;
@@ -93,7 +108,7 @@ inline bool gemm_nt_pair_shape_ok(long long M, long long N, long long K, long lo
   const long long lim = 0x80000000ll;
   if (N < 16 || N >= lim / 2 || N % 16 != 0) return false;
   if (!gemm_nt_shape_ok(M, 2 * N, K, lda, ldb, ld_pair, ld_pair, false)) return false;
-  if (ld_act % 8 != 0 || ld_act < N || ld_act >= lim || M * ld_act * 2 >= lim) return false;
+  if (ld_act % 8 != 0 || ld_act < N || ld_act >= lim || ld_act > ld_pair) return false;   // ld_pair bounds the row chunk
   return true;
 }
 

@@ -176,6 +176,9 @@ bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long 
 bool gemm_nt_pair_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ld_act,
                      long long ld_pair);
 void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st);
+// Rows one launch covers (the kernel's byte offsets stay below 2 GiB; gemm_nt() walks taller problems in row
+// ranges of this many rows). 0: not even one aligned range fits; callers refuse such operands.
+long long gemm_nt_rows_per_launch(const GemmNtArgs& a, int epi);
 void gemm_nt_set_variant(int v);   // benchmark knob, see csrc/gemm_nt.hip
 // out[C, R] = in[R, C]^T (bf16, R % 8 == 0 and C % 8 == 0, contiguous).
 void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);

@@ -153,8 +153,7 @@ def _dx_supported(dy2: torch.Tensor, w: torch.Tensor, aux=None) -> bool:
     N, K = w.shape
     if not (os.environ.get("DPA_LIBRARY_GEMM", "0") != "1" and dy2.is_cuda and dy2.dtype == torch.bfloat16
             and w.dtype == torch.bfloat16 and w.is_contiguous() and _rows_ok(dy2) and N % 64 == 0 and N >= 128
-            and K % 16 == 0 and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
-            and dy2.shape[0] * max(N, K) * 2 < 2 ** 31):
+            and K % 16 == 0 and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
         return False
     return aux is None or (aux.stride(1) == 1 and aux.stride(0) % 8 == 0 and aux.data_ptr() % 16 == 0)
 
@@ -321,7 +320,7 @@ def mlp_swiglu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tens
     up = two_up // 2
     if x2.shape[0] < GEMM_MIN_ROWS or two_up % 2 or tuple(w_proj.shape) != (C, up) or not w_proj.is_contiguous():
         return False
-    if not (up % 64 == 0 and up >= 128 and C % 64 == 0 and C >= 128 and x2.shape[0] * max(two_up, C) * 2 < 2 ** 31):
+    if not (up % 64 == 0 and up >= 128 and C % 64 == 0 and C >= 128):
         return False
     return bool(ops().gemm_nt_pair_supported(x2, w_fc, _EPI_SWIGLU, None))
 
@@ -343,7 +342,7 @@ def mlp_gelu_supported(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor
         return False
     # shapes of the second product and of the two input-gradient products
     return (up % 64 == 0 and up >= 128 and C % 64 == 0 and C >= 128 and w_proj.is_contiguous()
-            and tuple(w_proj.shape) == (C, up) and x2.shape[0] * max(up, C) * 2 < 2 ** 31)
+            and tuple(w_proj.shape) == (C, up))
 
 
 def mlp_gelu(x: torch.Tensor, w_fc: torch.Tensor, w_proj: torch.Tensor, sole_use: bool = False,

@@ -123,7 +123,12 @@ static void test_gemm_shapes() {
   CHECK(gemm_nt_shape_ok(65536, 768, 3072, 3072, 3072, 768, 768, false));
   CHECK(gemm_nt_shape_ok(8192, 50304, 768, 768, 768, 50304, 0, false));
   CHECK(!gemm_nt_shape_ok(8192, 50304, 768, 768, 768, 50304, 0, true));    // bias row would not fit in LDS
-  CHECK(!gemm_nt_shape_ok(65536, 50304, 768, 768, 768, 50304, 0, false));  // C passes 2 GiB
+  CHECK(gemm_nt_shape_ok(65536, 50304, 768, 768, 768, 50304, 0, false));   // C passes 2 GiB: walked in row ranges
+  CHECK(dpa::gemm_nt_row_chunk(65536, 50304, 256) == 21248);               // (2^31 - 1) / (50304 * 2), down to 256 rows
+  CHECK(dpa::gemm_nt_row_chunk(16384, 50304, 256) == 16384);               // fits: one launch
+  CHECK(dpa::gemm_nt_row_chunk(262144, 4096, 1024) == 261120);             // rotary forms cut at whole sequences
+  CHECK(21248ll * 50304 * 2 < 0x80000000ll && 261120ll * 4096 * 2 < 0x80000000ll);
+  CHECK(dpa::gemm_nt_pair_shape_ok(262144, 2048, 768, 768, 768, 2048, 4096));   // [gate | up] rows of 8 KiB, 2 GiB in all
   CHECK(!gemm_nt_shape_ok(64, 768, 96, 96, 96, 768, 0, false));            // K not a multiple of 64
   CHECK(!gemm_nt_shape_ok(64, 768, 64, 64, 64, 768, 0, false));            // K below two K-tiles
   CHECK(!gemm_nt_shape_ok(64, 760, 768, 768, 768, 760, 0, false));         // N not a multiple of 16
@@ -147,7 +152,8 @@ static void test_gemm_pair_shapes() {
   CHECK(!gemm_nt_pair_shape_ok(2100, 1080, 128, 128, 128, 1080, 2160));       // N not a multiple of 16
   CHECK(!gemm_nt_pair_shape_ok(2100, 1088, 128, 128, 128, 1088, 2000));       // pair pitch shorter than 2N
   CHECK(!gemm_nt_pair_shape_ok(2100, 1088, 128, 128, 128, 1000, 2176));       // activation pitch shorter than N
-  CHECK(!gemm_nt_pair_shape_ok(262144, 4096, 768, 768, 768, 4096, 8192));     // [M, 2N] passes 2 GiB
+  CHECK(gemm_nt_pair_shape_ok(262144, 4096, 768, 768, 768, 4096, 8192));      // [M, 2N] passes 2 GiB: row ranges
+  CHECK(!gemm_nt_pair_shape_ok(2100, 1088, 128, 128, 128, 4096, 2176));       // activation pitch wider than the pair's
   const long long big = 0x7fffffffffffffffll;
   CHECK(!gemm_nt_pair_shape_ok(64, big - 15, 768, 768, 768, big - 15, big - 15));
   CHECK(!gemm_nt_pair_shape_ok(64, (big / 2) & ~15ll, 768, 768, 768, 768, 768));

@@ -826,6 +826,48 @@ def test_gemm_nt_many_tiles_per_workgroup_is_race_free():
         assert torch.equal(first, again)
 
 
+def test_gemm_nt_rows_past_two_gib_run_as_row_ranges():
+    """Operands whose rows span 2 GiB and more (the kernel's own byte offsets stop there) are walked in row ranges:
+    add epilogue (output and auxiliary operand both re-based) and the two SwiGLU forms, checked on the rows around
+    the range boundaries and at both ends."""
+    o = _ops()
+    torch.manual_seed(11)
+    K, N = 128, 1024
+    M = (1 << 20) + 512                              # M * N * 2 bytes = 2 GiB + 1 MiB -> two ranges, the second 768 rows
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
+    x = torch.randn(M, N, device=DEV).bfloat16()
+    assert o.gemm_nt_supported(a, b, None, x)
+    c, _ = o.gemm_nt(a, b, None, 3, x)
+    cut = ((1 << 31) - 1) // (N * 2) // 256 * 256
+    rows = torch.tensor([0, 1, 255, 256, cut - 1, cut, cut + 1, cut + 255, cut + 256, M - 2, M - 1], device=DEV)
+    ref = a[rows].float() @ b.float().t() + x[rows].float()
+    assert rel_err(c[rows], ref) < 4e-3
+    del c, x
+    U, Ms = 2048, (1 << 18) + 256                    # [gate | up] rows of 8 KiB: 2 GiB at 262144 rows
+    a2 = a[:Ms]
+    w = (torch.randn(2 * U, K, device=DEV) / K ** 0.5).bfloat16()
+    assert o.gemm_nt_pair_supported(a2, w, 4, None)
+    act, h = o.gemm_nt(a2, w, None, 4, None)
+    cut = ((1 << 31) - 1) // (2 * U * 2) // 256 * 256
+    rows = torch.tensor([0, 255, cut - 1, cut, cut + 1, Ms - 1], device=DEV)
+    hf = a2[rows].float() @ w.float().t()
+    want = torch.nn.functional.silu(hf[:, :U]) * hf[:, U:]
+    assert (h[rows].float() - hf).abs().max() <= 2e-2 * hf.abs().max()
+    assert (act[rows].float() - want).abs().max() <= 2e-2 * want.abs().max() + 1e-3
+    del act
+    C = 256
+    dy = torch.randn(Ms, C, device=DEV).bfloat16()
+    wpt = (torch.randn(U, C, device=DEV) / C ** 0.5).bfloat16()
+    assert o.gemm_nt_pair_supported(dy, wpt, 5, h)
+    dh = o.gemm_nt(dy, wpt, None, 5, h)[0]
+    v = dy[rows].float() @ wpt.float().t()
+    g, u = h[rows].float()[:, :U], h[rows].float()[:, U:]
+    sg = torch.sigmoid(g)
+    assert (dh[rows][:, :U].float() - v * u * sg * (1 + g * (1 - sg))).abs().max() <= 2e-2 * (v * u).abs().max() + 1e-3
+    assert (dh[rows][:, U:].float() - v * g * sg).abs().max() <= 2e-2 * (v * g).abs().max() + 1e-3
+
+
 def test_transpose_bf16():
     x = torch.randn(3072, 768, device=DEV).bfloat16()
     assert torch.equal(_ops().transpose_bf16(x), x.t().contiguous())
