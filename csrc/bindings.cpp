@@ -1130,8 +1130,6 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const
   }
   TORCH_CHECK(dpa::gemm_nt_ok(rows, N, K, a.stride(0), ldw, N, ld_aux, false), "gemm_nt_grouped: unsupported shape ", rows,
               "x", N, "x", K);
-  TORCH_CHECK(rows * std::max<int64_t>(std::max<int64_t>(a.stride(0), N), ld_aux) * 2 < (int64_t(1) << 31),
-              "gemm_nt_grouped: the row-indexed operands must stay below 2 GiB (the grouped form is one launch)");
   Tensor c = at::empty({rows, N}, a.options());
   std::optional<Tensor> aux_out;
   dpa::GemmNtArgs g{};

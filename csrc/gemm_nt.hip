@@ -886,7 +886,6 @@ int g_gemm_nt_variant = 0;   // benchmark knob: bit 0 = one barrier per phase, b
 void gemm_nt_set_variant(int v) { g_gemm_nt_variant = v; }
 
 long long gemm_nt_rows_per_launch(const GemmNtArgs& a, int epi) {
-  if (a.w_ptrs != nullptr) return a.M;      // grouped mode indexes its weight table by absolute row block
   long long ldm = a.lda > a.ldc ? a.lda : a.ldc;
   if ((a.aux_in != nullptr || a.aux_out != nullptr) && a.ld_aux > ldm) ldm = a.ld_aux;
   long long align = 256;
@@ -911,6 +910,7 @@ void gemm_nt(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
     s.c = static_cast<char*>(a.c) + m0 * a.ldc * 2;
     if (a.aux_in != nullptr) s.aux_in = static_cast<const char*>(a.aux_in) + m0 * a.ld_aux * 2;
     if (a.aux_out != nullptr) s.aux_out = static_cast<char*>(a.aux_out) + m0 * a.ld_aux * 2;
+    if (a.w_ptrs != nullptr) s.block_group = a.block_group + m0 / 256;   // grouped mode: one entry per 256-row block
     gemm_nt_launch(s, epi, num_cus, st);
   }
 }

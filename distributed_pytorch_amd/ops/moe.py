@@ -302,9 +302,7 @@ def _nt_grouped_ok(x_flat, fc, proj, act: str, k: int = 8) -> bool:
     if not (use_hip(x_flat) and x_flat.dtype == torch.bfloat16 and hasattr(ops(), "gemm_nt_grouped")):
         return False
     U, C = fc[0].shape
-    rows_bound = x_flat.shape[0] * k + len(fc) * NT_BLOCK      # every byte offset of the kernel stays below 2 GiB
-    return (C % 64 == 0 and C >= 128 and U % 64 == 0 and U >= 128 and tuple(proj[0].shape) == (C, U)
-            and rows_bound * max(U, C) * 2 < 2 ** 31)
+    return C % 64 == 0 and C >= 128 and U % 64 == 0 and U >= 128 and tuple(proj[0].shape) == (C, U)
 
 
 class _GroupedExpertsNtFn(torch.autograd.Function):

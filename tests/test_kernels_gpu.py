@@ -1055,6 +1055,26 @@ def test_gemm_nt_grouped_matches_per_block_reference(epi):
         assert (c[blk].float() - want).abs().max() <= 2e-2 * want.abs().max() + 1e-3, (b, g)
 
 
+def test_gemm_nt_grouped_rows_past_two_gib():
+    """Grouped mode over more than 2 GiB of output rows: the row ranges carry their slice of the block table."""
+    o = torch.ops.dpa
+    torch.manual_seed(9)
+    G, N, K = 3, 1024, 128
+    nblk = (1 << 12) + 3                                   # 4099 blocks of 256 rows: 2 GiB + 1.5 MiB of output
+    rows = nblk * 256
+    a = torch.randn(rows, K, device="cuda").bfloat16()
+    ws = [(torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16() for _ in range(G)]
+    ptrs = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64, device="cuda")
+    groups = (torch.arange(nblk, device="cuda", dtype=torch.int32) * 7 + 1) % (G + 1)    # value G: no group
+    c, _ = o.gemm_nt_grouped(a, ptrs, N, K, 0, None, groups)
+    cut = ((1 << 31) - 1) // (N * 2) // 256                # first block of the second range
+    for b in (0, 1, cut - 1, cut, cut + 1, nblk - 1):
+        g = int(groups[b])
+        blk = slice(256 * b, 256 * (b + 1))
+        want = a[blk].float() @ ws[g].float().t() if g < G else torch.zeros(256, N, device="cuda")
+        assert (c[blk].float() - want).abs().max() <= 2e-2 * want.abs().max() + 1e-3, (b, g)
+
+
 def test_grouped_wgrad_on_the_256_kernel_matches():
     """Grouped mode of the dense 256 x 256 weight-gradient kernel (equal row chunks over the segments, combined
     atomically): per-segment dy^T x with an empty, a short and a multi-chunk segment, against fp32."""
