@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.normpath(os.path.join(os.path.dirname(os.path.abspath
 
 import torch  # noqa: E402
 
-from distributed_pytorch_amd.config import LLMconfig  # noqa: E402
+from distributed_pytorch_amd.config import LLMconfig, Trainconfig  # noqa: E402
 from distributed_pytorch_amd.models.llm import LLM  # noqa: E402
 from distributed_pytorch_amd.utils.tokenizer import get_encoder  # noqa: E402
 
@@ -37,8 +37,9 @@ def main(argv=None):
     ap.add_argument("--token_ids", action="store_true", help="print token ids instead of decoded text")
     args = ap.parse_args(argv)
 
-    # a file this framework wrote: it stores the configuration objects, hence the full loader
-    ckpt = torch.load(args.ckpt, map_location="cpu", weights_only=False)
+    # the checkpoint stores the two configuration objects next to the tensors: allow exactly those classes
+    with torch.serialization.safe_globals([LLMconfig, Trainconfig]):
+        ckpt = torch.load(args.ckpt, map_location="cpu", weights_only=True)
     cfg = LLMconfig(**ckpt["model_config_dict"]).finalize()
     model = LLM(cfg)
     model.load_state_dict(ckpt["model_state"])
