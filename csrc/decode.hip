@@ -1,6 +1,6 @@
 // Decode-step linear layer for gfx950: one launch computes
 //
-//     y[B, N] = act( LN(x)[B, K] * W[N, K]^T + bias ) + residual          (B <= 16 rows, bf16, fp32 accumulate)
+//     y[B, N] = act( LN(x)[B, K] * W[N, K]^T + bias ) + residual          (B <= 64 rows, bf16, fp32 accumulate)
 //
 // A decode step of a transformer block is a chain of matrix-vector-sized products, each preceded or
 // followed by a LayerNorm, a bias, an activation or a residual add. As separate launches (LayerNorm,
@@ -10,7 +10,8 @@
 // residual are the epilogue, and the key / value columns of a fused qkv projection can be written
 // straight into the preallocated KV cache at the device-side position, so a dense block is five launches.
 //
-// Structure: one 256-thread workgroup per 16 output features. The activations sit in LDS as bf16 (rows
+// Structure: one 256-thread workgroup per 16 output features and group of 16 rows (blockIdx.y; the groups of a
+// larger batch read the same weights, from L2 after the first). The activations sit in LDS as bf16 (rows
 // padded by 16 bytes; only the B real rows, so 8 rows of width 8192 still fit). v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as the row operand:
 // a lane's 16-byte global load of W[n0 + lane % 16][k0 + 8 (lane / 16) ..] is exactly its fragment, no LDS
 // and no cross-lane reduction for the weights; the activation fragment is one ds_read_b128. The four waves
@@ -56,10 +57,12 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int K = p.K, B = p.B;
+  const int K = p.K;
+  const int row0 = blockIdx.y * 16;                      // this workgroup's rows: row0 .. row0 + B - 1
+  const int B = p.B - row0 < 16 ? p.B - row0 : 16;
   const int xstride = K * 2 + 16;                        // bytes per staged row
   float* part = reinterpret_cast<float*>(smem + B * xstride);    // [pair][wave][lane][4]
-  const bf16_t* x = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* x = reinterpret_cast<const bf16_t*>(p.x) + (long long)row0 * p.ldx;
 
   // ---- weight fragments of this wave's quarter of K (pairs: 16 gate + the 16 matching up rows) ----
   const int n0 = blockIdx.x * 16;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
       if (kPair) bw2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.bias) + p.N + n);
     }
     if (p.residual != nullptr && l15 < B)
-      rr = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.residual) + (long long)l15 * p.ldr + n);
+      rr = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.residual) + (long long)(row0 + l15) * p.ldr + n);
   }
 
   // ---- stage the activations: LayerNorm (fp32 statistics, two passes over registers) or a copy (rows past B are not staged) ----
@@ -224,13 +227,13 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
   u32x2 o;
   o[0] = pack_bf16x2(v[0], v[1]);
   o[1] = pack_bf16x2(v[2], v[3]);
-  bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + (long long)l15 * p.ldy + n;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + (long long)(row0 + l15) * p.ldy + n;
   if (p.k_cache != nullptr && n0 >= p.kv_col0) {
     // key / value columns of a fused qkv projection: row `pos` of the preallocated caches [B, S, kv_cols]
     const long long pos = *p.pos;
     const bool is_k = n0 < p.kv_col0 + p.kv_cols;
     bf16_t* cache = reinterpret_cast<bf16_t*>(is_k ? p.k_cache : p.v_cache);
-    dst = cache + (long long)l15 * p.cache_bs + pos * p.kv_cols + (n - p.kv_col0 - (is_k ? 0 : p.kv_cols));
+    dst = cache + (long long)(row0 + l15) * p.cache_bs + pos * p.kv_cols + (n - p.kv_col0 - (is_k ? 0 : p.kv_cols));
   }
   *reinterpret_cast<u32x2*>(dst) = o;
 }
@@ -242,22 +245,22 @@ static bool wide_split(const DecodeLinearArgs& p) {
 }
 
 bool decode_linear_ok(long long B, long long N, long long K, long long ldx, long long ldw, bool pair, bool has_ln) {
-  const long long lds = B * (K * 2 + 16) + (pair ? 2 : 1) * 16384;   // the staged rows + the waves' partial tiles
+  const long long lds = (B < 16 ? B : 16) * (K * 2 + 16) + (pair ? 2 : 1) * 16384;   // the staged rows + the waves' partial tiles
   if (has_ln && K > 512 * kLnVec) return false;   // the LayerNorm prologue keeps a row in registers
-  return B >= 1 && B <= 16 && N >= 16 && N % 16 == 0 && K >= 128 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
+  return B >= 1 && B <= kDecodeMaxRows && N >= 16 && N % 16 == 0 && K >= 128 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
          lds <= 160 * 1024;
 }
 
 template <int ACT, int NW, bool LN>
 static void launch(const DecodeLinearArgs& p, hipStream_t st) {
-  const size_t lds = (size_t)p.B * ((size_t)p.K * 2 + 16) + (ACT == kDecodeSwiglu ? 2 : 1) * NW * 1024;
+  const size_t lds = (size_t)(p.B < 16 ? p.B : 16) * ((size_t)p.K * 2 + 16) + (ACT == kDecodeSwiglu ? 2 : 1) * NW * 1024;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)decode_linear_kernel<ACT, NW, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((decode_linear_kernel<ACT, NW, LN>), dim3(p.N / 16), dim3(NW * 64), lds, st, p);
+  hipLaunchKernelGGL((decode_linear_kernel<ACT, NW, LN>), dim3(p.N / 16, (p.B + 15) / 16), dim3(NW * 64), lds, st, p);
 }
 
 void decode_linear(const DecodeLinearArgs& p, hipStream_t st) {

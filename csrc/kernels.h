@@ -184,7 +184,7 @@ void gemm_nt_set_variant(int v);   // benchmark knob, see csrc/gemm_nt.hip
 void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
 
 // ---- Decode-step linear layer (csrc/decode.hip) ------------------------------------------------------
-// y[B, N] = act(LN(x)[B, K] * w[N, K]^T + bias) + residual for B <= 16 rows (bf16, fp32 accumulation), one launch.
+// y[B, N] = act(LN(x)[B, K] * w[N, K]^T + bias) + residual for B <= 64 rows (bf16, fp32 accumulation), one launch.
 //   ln_w == nullptr: no LayerNorm (ln_b may be nullptr with ln_w set: no shift)
 //   act kDecodeSwiglu: w is [2N, K] (gate rows, then up rows), bias [2N]: y = silu(gate) * up
 //   k_cache != nullptr: output columns [kv_col0, kv_col0 + kv_cols) go to row *pos of k_cache [B, S, kv_cols]
@@ -192,6 +192,7 @@ void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
 // N % 16 == 0, K % 128 == 0 (K <= 2048 with the LayerNorm), kv_col0 % 16 == 0, kv_cols % 16 == 0 (decode_linear_ok
 // checks the sizes).
 enum { kDecodeNone = 0, kDecodeGelu = 1, kDecodeSwiglu = 2 };
+constexpr int kDecodeMaxRows = 64;   // rows of one call: groups of 16 share a launch (and the weights, through L2)
 struct DecodeLinearArgs {
   const void* x;
   long long ldx;

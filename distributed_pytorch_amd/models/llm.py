@@ -537,10 +537,10 @@ class Block(nn.Module):
 
     # ---- cached decode step on the fused decode kernels ----------------------------------------------
     def _decode_ok(self, x) -> bool:
-        """One new token per sequence, at most 16 sequences, dense GQA-family block with a GELU or SwiGLU
+        """One new token per sequence, at most 64 sequences, dense GQA-family block with a GELU or SwiGLU
         feed-forward, bf16 on the GPU: the step runs as five launches (``ops.decode_linear``)."""
         if not (self.gqa and not self.is_moe and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 1
-                and x.shape[0] <= 16 and self.mlp.non_linearity in ("gelu", "swiglu")):
+                and x.shape[0] <= 64 and self.mlp.non_linearity in ("gelu", "swiglu")):
             return False
         key = (x.shape[0], x.device)
         ok = getattr(self, "_decode_ok_cache", {}).get(key)

@@ -1,4 +1,4 @@
-"""Decode-step linear layer: ``y = act(LN(x) @ w.T + bias) + residual`` for at most 16 rows in ONE launch
+"""Decode-step linear layer: ``y = act(LN(x) @ w.T + bias) + residual`` for at most 64 rows in ONE launch
 (``csrc/decode.hip``), optionally writing the key / value columns of a fused qkv projection straight into
 the preallocated KV cache at the device-side position.
 
@@ -22,7 +22,7 @@ ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
 
 
 def decode_linear_supported(x2: torch.Tensor, w: torch.Tensor, act: int = ACT_NONE, has_ln: bool = False) -> bool:
-    """``x2 [B <= 16, K]`` and ``w [N (2N for SwiGLU), K]`` bf16 on the GPU, K % 128 == 0 (and at most 2048
+    """``x2 [B <= 64, K]`` and ``w [N (2N for SwiGLU), K]`` bf16 on the GPU, K % 128 == 0 (and at most 2048
     with the LayerNorm prologue), N % 16 == 0."""
     if os.environ.get("DPA_FUSED_DECODE", "1") == "0":
         return False

@@ -1158,7 +1158,7 @@ def test_qkv_rope_attention_fused_matches_separate_passes(nh, nkv, hs):
 
 
 @pytest.mark.parametrize("B,N,K", [(1, 768, 768), (8, 2304, 768), (16, 768, 3072), (3, 1024, 256), (5, 50304, 768),
-                                   (8, 2048, 8192), (7, 8192, 2048)])
+                                   (8, 2048, 8192), (7, 8192, 2048), (17, 768, 768), (37, 2304, 768), (64, 768, 3072)])
 @pytest.mark.parametrize("form", ["plain", "ln_bias", "ln_gelu", "bias_residual", "ln_swiglu"])
 def test_decode_linear_forms_match_fp32(B, N, K, form):
     """The one-launch decode-step linear layer (LayerNorm prologue, bias / GELU / SwiGLU / residual
@@ -1191,10 +1191,11 @@ def test_decode_linear_forms_match_fp32(B, N, K, form):
     assert torch.allclose(got.float(), want, atol=4e-2, rtol=3e-2)
 
 
-def test_decode_linear_writes_new_key_value_rows_into_the_cache():
+@pytest.mark.parametrize("batch", [4, 35])
+def test_decode_linear_writes_new_key_value_rows_into_the_cache(batch):
     from distributed_pytorch_amd import ops
     torch.manual_seed(0)
-    B, S, nh, nkv, hs, K = 4, 32, 8, 2, 64, 512
+    B, S, nh, nkv, hs, K = batch, 32, 8, 2, 64, 512
     W = (nh + 2 * nkv) * hs
     x = torch.randn(B, K, device="cuda").bfloat16()
     w = (torch.randn(W, K, device="cuda") / math.sqrt(K)).bfloat16()
