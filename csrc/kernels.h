@@ -192,7 +192,7 @@ void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
 // N % 16 == 0, K % 128 == 0 (K <= 2048 with the LayerNorm), kv_col0 % 16 == 0, kv_cols % 16 == 0 (decode_linear_ok
 // checks the sizes).
 enum { kDecodeNone = 0, kDecodeGelu = 1, kDecodeSwiglu = 2 };
-constexpr int kDecodeMaxRows = 64;   // rows of one call: groups of 16 share a launch (and the weights, through L2)
+constexpr int kDecodeMaxRows = 64;   // rows of one call: groups of 16 share a launch (and the weights, through L2); from ~128 rows on the library GEMMs are faster
 struct DecodeLinearArgs {
   const void* x;
   long long ldx;
