@@ -235,10 +235,12 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
 // per split without a second pass over dY.
 //
 // GROUPED: one product per row segment (the experts of a MoE layer in the padded expert-sorted layout), the
-// segment bounds read from device memory. Work item = (output tile, chunk of `mper` rows); the chunks are
-// numbered through the segments (segment s owns ceil(rows_s / mper) of them), so every workgroup has the same
-// amount of work whatever the routing did — early in training two of eight experts can hold 90 % of the rows.
-// Partial tiles are added into the zero-initialised fp32 [segments, N, K] result with float atomics.
+// segment bounds read from device memory. Rows are counted in chunks of `mper`, numbered through the segments
+// (segment s owns ceil(rows_s / mper) of them); a work item = (output tile, an equal share of consecutive chunks),
+// so every workgroup has the same amount of work whatever the routing did — early in training two of eight
+// experts can hold 90 % of the rows. A workgroup walks the segments its share overlaps: one accumulation per
+// segment, added into the zero-initialised fp32 [segments, N, K] result with float atomics (one 256 KiB tile per
+// workgroup and segment boundary crossed, not one per chunk).
 // (one wave per SIMD by construction — 128 KiB of LDS per workgroup —, stated to the register allocator so that all
 // 256 accumulators stay in AGPRs in every instantiation)
 template <bool ACCUM, bool BIAS, bool GROUPED = false>
@@ -263,25 +265,43 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
   const int wn = wave >> 1, wk = wave & 1;
-  int seg = 0, m_begin, m_end;
+  int seg = 0, m_begin = 0, m_end = 0;
+  // grouped mode: this workgroup's chunks [c_lo, c_hi) of the chunk numbering that runs through the segments;
+  // c0 = number of the first chunk of segment `seg`, seg_nch = chunks of that segment
+  int c_lo = 0, c_hi = 0, c0 = 0, seg_nch = 0;
   if (GROUPED) {
-    int c = split, len = 0;
-    for (seg = 0; seg < nseg; ++seg) {
-      len = (int)seg_rows[seg];
-      const int nch = (len + mper - 1) / mper;
-      if (c < nch) break;
-      c -= nch;
-    }
-    if (seg == nseg) return;   // past the last chunk (the grid is sized for the worst case)
-    const int base = (int)seg_start[seg];
-    m_begin = base + c * mper;
-    m_end = m_begin + mper;
-    if (m_end > base + len) m_end = base + len;
+    int total = 0;
+    for (int s = 0; s < nseg; ++s) total += ((int)seg_rows[s] + mper - 1) / mper;
+    const int nitems = gridDim.x / ntile;
+    const int cper = (total + nitems - 1) / nitems;
+    c_lo = split * cper;
+    c_hi = c_lo + cper < total ? c_lo + cper : total;
     split = 0;
+    if (c_lo >= c_hi) return;
   } else {
     m_begin = split * mper;
     m_end = m_begin + mper;
     if (m_end > M) m_end = M;
+  }
+  for (;;) {   // one pass per row range: the only one in the dense modes, one per overlapped segment in grouped mode
+  if (GROUPED) {
+    bool found = false;
+    for (; seg < nseg; ++seg) {
+      const int len = (int)seg_rows[seg];
+      seg_nch = (len + mper - 1) / mper;
+      const int lo = c_lo > c0 ? c_lo : c0, hi = c_hi < c0 + seg_nch ? c_hi : c0 + seg_nch;
+      if (lo < hi) {
+        const int base = (int)seg_start[seg];
+        m_begin = base + (lo - c0) * mper;
+        m_end = base + (hi - c0) * mper;
+        if (m_end > base + len) m_end = base + len;
+        found = true;
+        break;
+      }
+      c0 += seg_nch;
+      if (c0 >= c_hi) break;
+    }
+    if (!found) break;
   }
   const int ntiles = (m_end > m_begin) ? (m_end - m_begin) / 64 : 0;
 
@@ -366,6 +386,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         else *p = acc[i][j][r];
       }
     }
+  if (!GROUPED) break;
+  // next segment; every wave is done with the LDS stages before the next range's first transfer lands in them
+  c0 += seg_nch;
+  ++seg;
+  __builtin_amdgcn_s_barrier();
+  }
 }
 
 // out (bf16 or fp32) = [out +] sum over `nslabs` slabs of ws
@@ -520,7 +546,7 @@ void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, 
                        ldy, ldx, sp, mper);
 }
 
-constexpr int kGroupedChunk = 4096;   // rows per work item: 64 LDS tiles, ~130 us; 256 KiB of atomics per item
+constexpr int kGroupedChunk = 256;   // granularity of the row split (4 LDS tiles); a workgroup takes a run of chunks
 
 bool wgrad3_grouped_ok(long long rows, int N, int K) { return rows % 64 == 0 && rows > 0 && N % 256 == 0 && K % 256 == 0; }
 
@@ -533,8 +559,13 @@ void wgrad3_grouped(const void* dy, const void* x, float* out, const long long* 
                               131072);
     attr = true;
   }
-  const int max_chunks = rows / kGroupedChunk + nseg;
-  const dim3 grid((N / 256) * (K / 256) * max_chunks), block(256);
+  // one workgroup per CU: row shares so that tiles * shares fills the 256 CUs once (at least 1024 rows per share)
+  const int tiles = (N / 256) * (K / 256);
+  int items = 256 / tiles;
+  const int max_items = rows / 1024;
+  if (items > max_items) items = max_items;
+  if (items < 1) items = 1;
+  const dim3 grid(tiles * items), block(256);
   hipLaunchKernelGGL((wgrad3_kernel<false, false, true>), grid, block, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, out,
                      (float*)nullptr, rows, N, K, ldy, ldx, 1, kGroupedChunk, seg_start, seg_rows, nseg);
 }
