@@ -23,7 +23,7 @@ def timeit(fn, n=10):
 
 
 E = 8
-for pairs, N, K in ((32768, 3072, 768), (131072, 3072, 768), (131072, 768, 3072)):
+for pairs, N, K in ((16384, 3072, 768), (32768, 3072, 768), (65536, 3072, 768), (131072, 3072, 768), (131072, 768, 3072), (524288, 3072, 768)):
     for skew in (0.0, 0.3):
         w = torch.tensor([1.0 + skew * ((i % 3) - 1) for i in range(E)])
         seg = ((w / w.sum() * pairs).long() + 255) // 256 * 256

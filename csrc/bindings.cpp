@@ -692,9 +692,9 @@ Tensor grouped_gemm(const Tensor& a, const Tensor& w_ptrs, int64_t w_rows, int64
   return c;
 }
 
-// The grouped mode of the dense 256 x 256 weight-gradient kernel takes over from 96 K rows on (24 chunks x 36 tiles
-// fill the chip several times over): 108 vs 110-113 ms per gpt-moe-8x step at micro-batch 64, where two of eight
-// experts can hold 90 % of the rows early in training; below that the 128 x 128 kernel's finer tiles win
+// The grouped mode of the dense 256 x 256 weight-gradient kernel takes over from 24 K rows on: equal row shares per
+// workgroup whatever the routing did (two of eight experts can hold 90 % of the rows early in training), 676-1014 TF
+// from 32 K to 512 K rows against 570-680 TF for the 128 x 128 kernel, whose finer tiles win below
 // (benchmarks/grouped_wgrad_bench.py). grouped_wgrad_use_wgrad3(false) / DPA_MOE_WGRAD3=0 turns it off.
 bool g_grouped_wgrad3 = true;
 bool g_grouped_wgrad3_any_size = false;   // tests: take the 256 x 256 kernel whatever the row count
@@ -713,8 +713,8 @@ Tensor grouped_wgrad(const Tensor& dy, const Tensor& x, const Tensor& seg_start,
                   seg_rows.is_cuda() && seg_rows.scalar_type() == at::kLong && seg_rows.is_contiguous() &&
                   seg_rows.numel() == G,
               "grouped_wgrad: segment tables are int64 cuda [G]");
-  if (dpa::wgrad3_grouped_ok(M, (int)N, (int)K) && g_grouped_wgrad3 && (M >= 98304 || g_grouped_wgrad3_any_size)) {
-    // the dense layers' 256 x 256 kernel over equal row chunks of the segments, partial tiles added atomically
+  if (dpa::wgrad3_grouped_ok(M, (int)N, (int)K) && g_grouped_wgrad3 && (M >= 24576 || g_grouped_wgrad3_any_size)) {
+    // the dense layers' 256 x 256 kernel over equal row shares of the segments, partial tiles added atomically
     Tensor out = at::zeros({G, N, K}, dy.options().dtype(at::kFloat));
     dpa::wgrad3_grouped(dy.data_ptr(), x.data_ptr(), out.data_ptr<float>(), (const long long*)seg_start.data_ptr<int64_t>(),
                         (const long long*)seg_rows.data_ptr<int64_t>(), (int)G, (int)M, (int)N, (int)K, dy.stride(0),
