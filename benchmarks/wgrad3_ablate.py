@@ -27,10 +27,15 @@ x = torch.randn(8192, 1024, device="cuda").bfloat16()
 ref = dy.float().t() @ x.float()
 got = hip().wgrad2(dy, x).float()
 print(f"check: max relative error {((got - ref).abs().max() / ref.abs().max()).item():.2e}")
+_, db = hip().wgrad2_slabs_bias(dy, x)
+refb = dy.float().sum(0)
+print(f"check: bias gradient max relative error {((db.float() - refb).abs().max() / refb.abs().max()).item():.2e}")
 for M in (65536, 262144):
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         dy = torch.randn(M, N, device="cuda").bfloat16()
         x = torch.randn(M, K, device="cuda").bfloat16()
         t = timeit(lambda: hip().wgrad2(dy, x))
-        print(f"M={M:6d} dW[{N:4d},{K:4d}]  {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TF", flush=True)
+        tb = timeit(lambda: hip().wgrad2_slabs_bias(dy, x))
+        print(f"M={M:6d} dW[{N:4d},{K:4d}]  {t * 1e3:8.1f} us  {2.0 * M * N * K / t / 1e9:7.1f} TF   with the bias gradient (slabs, no fold) {tb * 1e3:8.1f} us",
+              flush=True)
         del dy, x

@@ -836,10 +836,10 @@ std::tuple<Tensor, Tensor> wgrad2_slabs_bias(const Tensor& dy, const Tensor& x) 
   const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
   Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
   if (dpa::wgrad2_fuses_bias((int)M, (int)N, (int)K)) {
-    Tensor bslabs = at::empty({splits, N}, dy.options().dtype(at::kFloat));
+    Tensor bslabs = at::empty({dpa::wgrad2_bias_slabs((int)M, (int)N, (int)K), N}, dy.options().dtype(at::kFloat));
     dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
                      x.stride(0), splits, cur_stream(), bslabs.data_ptr<float>());
-    return {slabs, splits == 1 ? bslabs.view({N}) : bslabs.sum(0)};
+    return {slabs, bslabs.sum(0)};
   }
   dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
                    x.stride(0), splits, cur_stream());
@@ -863,10 +863,11 @@ void wgrad2_direct(const Tensor& dy, const Tensor& x, Tensor dw_acc, const std::
   const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
   Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
   if (db_acc.has_value() && dpa::wgrad2_fuses_bias((int)M, (int)N, (int)K)) {
-    Tensor bslabs = at::empty({splits, N}, dy.options().dtype(at::kFloat));
+    const int bs = dpa::wgrad2_bias_slabs((int)M, (int)N, (int)K);
+    Tensor bslabs = at::empty({bs, N}, dy.options().dtype(at::kFloat));
     dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
                      x.stride(0), splits, cur_stream(), bslabs.data_ptr<float>());
-    dpa::wgrad_finish(bslabs.data_ptr<float>(), db_acc->data_ptr(), N, splits, true, is_bf16(*db_acc), cur_stream());
+    dpa::wgrad_finish(bslabs.data_ptr<float>(), db_acc->data_ptr(), N, bs, true, is_bf16(*db_acc), cur_stream());
   } else {
     dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
                      x.stride(0), splits, cur_stream());

@@ -230,9 +230,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ 
 // two 64 KiB stages, filled by LDS-DMA issued from inline assembly (see dma_rows64x128_asm in mfma_tiles.h) so that
 // the transfer of tile t+1 stays in flight during the MFMAs of tile t.
 //
-// BIAS: the workgroups of the first K-tile column also sum their dY fragments over the tokens on the
-// otherwise idle VALU (each lane adds the 8 tokens of its column), giving the bias gradient
-// per split without a second pass over dY.
+// BIAS: the waves also sum their dY fragments over the tokens on the otherwise idle VALU (each lane adds
+// the 8 tokens of its column; the waves that hold the same fragments share the token steps), giving partial
+// bias gradients without a second pass over dY.
 //
 // GROUPED: one product per row segment (the experts of a MoE layer in the padded expert-sorted layout), the
 // segment bounds read from device memory. Rows are counted in chunks of `mper`, numbered through the segments
@@ -312,8 +312,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  // bias gradient: the 2 * tiles_k waves that hold the same dY fragments (both wk of every K-tile column) take
+  // the token steps in turn, so the column sums cost every wave a sixth (K = 768) of what one wave would pay
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = BIAS && tk == 0 && wk == 0;
+  const int bias_q = 2 * tiles_k, bias_me = 2 * tk + wk;
+  int bias_cnt = bias_me;      // token steps until this wave's next turn
 
   const unsigned lds0 = (unsigned)(size_t)(dma_lptr_t)smem;
   auto issue = [&](int t, int stage) {
@@ -352,21 +355,25 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-      if (do_bias) {
+      if (BIAS) {
+        if (bias_cnt == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const u32x4 v = __builtin_bit_cast(u32x4, a[i]);
+          for (int i = 0; i < 4; ++i) {
+            const u32x4 v = __builtin_bit_cast(u32x4, a[i]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bsum[i] += lo_bf16(v[e]) + hi_bf16(v[e]);
+            for (int e = 0; e < 4; ++e) bsum[i] += lo_bf16(v[e]) + hi_bf16(v[e]);
+          }
+          bias_cnt = bias_q;
         }
+        --bias_cnt;
       }
     }
   }
-  if (do_bias) {
+  if (BIAS) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      if (hh == 0) bias_slabs[(long long)split * N + n0 + 128 * wn + 32 * i + (lane & 31)] = tot;
+      if (hh == 0) bias_slabs[((long long)split * bias_q + bias_me) * N + n0 + 128 * wn + 32 * i + (lane & 31)] = tot;
     }
   }
 
@@ -510,6 +517,8 @@ int wgrad2_splits(int M, int N, int K) {
 void wgrad2_set_stages(int s) { g_wgrad2_stages = s; }
 
 bool wgrad2_fuses_bias(int M, int N, int K) { return use_wgrad3(M, N, K); }
+// rows of the fp32 [rows, N] partial bias sums the fused form writes (every one is written: sum them all)
+int wgrad2_bias_slabs(int M, int N, int K) { return wgrad2_splits(M, N, K) * 2 * (K / 256); }
 
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
                  int splits, hipStream_t st, float* bias_slabs) {

@@ -114,9 +114,10 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 bool wgrad2_ok(int M, int N, int K);
 int wgrad2_splits(int M, int N, int K);
 void wgrad2_set_stages(int s);
-// bias_slabs (optional, only when wgrad2_fuses_bias(M, N, K) and splits > 0): fp32 [splits, N] receiving the
-// per-split column sums of dy (the bias gradient), produced inside the same kernel.
+// bias_slabs (optional, only when wgrad2_fuses_bias(M, N, K) and splits > 0): fp32 [wgrad2_bias_slabs(M, N, K), N]
+// receiving partial column sums of dy (their sum is the bias gradient), produced inside the same kernel.
 bool wgrad2_fuses_bias(int M, int N, int K);
+int wgrad2_bias_slabs(int M, int N, int K);   // rows of bias_slabs (all written; their sum is the bias gradient)
 // Per-segment weight gradients on the 256 x 256 kernel (segment bounds in device memory, multiples of 64 rows),
 // work divided in equal row chunks across the segments: out = fp32 [nseg, N, K], zero-initialised by the caller,
 // receives the partial tiles through float atomics. N % 256 == 0, K % 256 == 0.
