@@ -4,7 +4,7 @@ MI355X, compared against a committed table.
 
     python benchmarks/perf_regression.py                 # measure, compare with benchmarks/perf_baseline_mi355x.json
     python benchmarks/perf_regression.py --update        # measure and rewrite the table
-    python benchmarks/perf_regression.py --only gemm     # a subset (substring of the entry names)
+    python benchmarks/perf_regression.py --only gemm     # a subset (substring of the entry names; with --update the other entries are kept)
     python benchmarks/perf_regression.py --tolerance 0.1 # allowed slowdown (default 0.08: boxes of one pool differ by 2-4 %)
 
 Every entry is a time in microseconds (median of a few timed calls; decode-step kernels are replayed from a hipGraph
@@ -112,6 +112,14 @@ def entries():
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         wgrad(N, K)
 
+    def grouped_wgrad():
+        seg = torch.full((8,), 16384, dtype=torch.int64)
+        start = torch.cumsum(seg, 0) - seg
+        dy, x = bf(131072, 3072), bf(131072, 768)
+        ss, sr = start.to(DEV), seg.to(DEV)
+        return median_us(lambda: hip().grouped_wgrad(dy, x, ss, sr), n=10)
+    E["grouped weight gradient 8 x 16384 rows N3072 K768"] = grouped_wgrad
+
     def attn(B, T, nh, nkv, hs):
         def setup():
             q, k, v = bf(B, T, nh, hs), bf(B, T, nkv, hs), bf(B, T, nkv, hs)
@@ -180,6 +188,12 @@ def entries():
             r = bf(8, N) if res else None
             return graph_us(lambda: ops.decode_linear(x, lnp, w, b, r, act))
         E[f"decode step (graph) {name} B8 K{K} N{N}"] = run
+
+    def dec64():
+        x, w, b = bf(64, 768), bf(2304, 768, scale=768 ** -0.5), bf(2304)
+        lnp = (bf(768), bf(768), 1e-5)
+        return graph_us(lambda: ops.decode_linear(x, lnp, w, b, None, ops.ACT_NONE))
+    E["decode step (graph) LayerNorm + qkv + bias B64 K768 N2304"] = dec64
 
     dec("LayerNorm + qkv + bias", 768, 2304, True, True, False, ops.ACT_NONE)
     dec("projection + bias + residual", 768, 768, False, True, True, ops.ACT_NONE)
