@@ -1109,29 +1109,42 @@ Tensor decode_linear(const Tensor& x, const std::optional<Tensor>& ln_w, const s
 }
 
 // Grouped form of the NT GEMM (csrc/gemm_nt.hip): c[rows, N] = epi(a[rows, K] * W_g^T) with W_g = the [N, K] matrix
-// at address w_ptrs[block_group[row / 256]]. epi: 0 none, 1 GELU (also returns GELU'), 2 multiply by aux [rows, N].
+// at address w_ptrs[block_group[row / 256]]. epi: 0 none, 1 GELU (also returns GELU'), 2 multiply by aux [rows, N],
+// 4 SwiGLU (W_g = [2N, K], gate rows then up rows: returns silu(gate) * up [rows, N] and [gate | up] [rows, 2N]),
+// 5 dSwiGLU (aux = [gate | up] [rows, 2N]: returns [dgate | dup] [rows, 2N] from d(act) = a W_g^T).
 std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const Tensor& w_ptrs, int64_t N, int64_t ldw,
                                                          int64_t epi, const std::optional<Tensor>& aux,
                                                          const Tensor& block_group) {
   check_rows2d(a, "a");
   const int64_t rows = a.size(0), K = a.size(1);
-  TORCH_CHECK(epi == dpa::kEpiNone || epi == dpa::kEpiGelu || epi == dpa::kEpiMul, "gemm_nt_grouped: epilogue 0, 1 or 2");
-  TORCH_CHECK((epi == dpa::kEpiMul) == aux.has_value(), "gemm_nt_grouped: the multiply epilogue (and only it) takes aux");
+  const bool pair = epi == dpa::kEpiSwiglu || epi == dpa::kEpiDswiglu;
+  TORCH_CHECK(epi == dpa::kEpiNone || epi == dpa::kEpiGelu || epi == dpa::kEpiMul || pair,
+              "gemm_nt_grouped: epilogue 0, 1, 2, 4 or 5");
+  TORCH_CHECK((epi == dpa::kEpiMul || epi == dpa::kEpiDswiglu) == aux.has_value(),
+              "gemm_nt_grouped: the multiply and dSwiGLU epilogues (and only they) take aux");
   TORCH_CHECK(rows % 256 == 0 && rows > 0, "gemm_nt_grouped: rows must be padded to a multiple of 256");
   TORCH_CHECK(w_ptrs.is_cuda() && w_ptrs.scalar_type() == at::kLong && w_ptrs.is_contiguous() && w_ptrs.numel() >= 1,
               "w_ptrs: int64 cuda");
   TORCH_CHECK(block_group.is_cuda() && block_group.scalar_type() == at::kInt && block_group.is_contiguous() &&
                   block_group.numel() == rows / 256,
               "block_group: int32 [rows / 256]");
-  int64_t ld_aux = N;
+  const int64_t aux_cols = pair ? 2 * N : N;
+  int64_t ld_aux = aux_cols;
   if (aux.has_value()) {
     check_rows2d(*aux, "aux");
-    TORCH_CHECK(aux->size(0) == rows && aux->size(1) == N, "gemm_nt_grouped: aux is [rows, N]");
+    TORCH_CHECK(aux->size(0) == rows && aux->size(1) == aux_cols, "gemm_nt_grouped: aux is [rows, N] ([rows, 2N] for dSwiGLU)");
     ld_aux = aux->stride(0);
   }
-  TORCH_CHECK(dpa::gemm_nt_ok(rows, N, K, a.stride(0), ldw, N, ld_aux, false), "gemm_nt_grouped: unsupported shape ", rows,
-              "x", N, "x", K);
-  Tensor c = at::empty({rows, N}, a.options());
+  const int64_t c_cols = epi == dpa::kEpiDswiglu ? 2 * N : N;
+  if (pair) {
+    TORCH_CHECK(dpa::gemm_nt_pair_ok(rows, N, K, a.stride(0), ldw, N, ld_aux) &&
+                    dpa::gemm_nt_pair_ok(rows, N, K, a.stride(0), ldw, N, 2 * N),
+                "gemm_nt_grouped: unsupported SwiGLU shape ", rows, "x", N, "x", K);
+  } else {
+    TORCH_CHECK(dpa::gemm_nt_ok(rows, N, K, a.stride(0), ldw, N, ld_aux, false), "gemm_nt_grouped: unsupported shape ", rows,
+                "x", N, "x", K);
+  }
+  Tensor c = at::empty({rows, c_cols}, a.options());
   std::optional<Tensor> aux_out;
   dpa::GemmNtArgs g{};
   g.a = a.data_ptr();
@@ -1142,10 +1155,10 @@ std::tuple<Tensor, std::optional<Tensor>> gemm_nt_grouped(const Tensor& a, const
   g.K = (int)K;
   g.lda = a.stride(0);
   g.ldb = ldw;
-  g.ldc = N;
+  g.ldc = c_cols;
   g.ld_aux = ld_aux;
-  if (epi == dpa::kEpiGelu) {
-    aux_out = at::empty({rows, N}, a.options());
+  if (epi == dpa::kEpiGelu || epi == dpa::kEpiSwiglu) {
+    aux_out = at::empty({rows, aux_cols}, a.options());
     g.aux_out = aux_out->data_ptr();
   } else if (aux.has_value()) {
     g.aux_in = aux->data_ptr();

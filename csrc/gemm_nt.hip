@@ -954,7 +954,7 @@ static void gemm_nt_launch(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
 #undef DPA_GNT_ABL
   }
 #endif
-  if (a.w_ptrs != nullptr) {   // grouped mode: bias-free, epilogues none / GELU / multiply
+  if (a.w_ptrs != nullptr) {   // grouped mode: bias-free, epilogues none / GELU / multiply / SwiGLU / dSwiGLU
 #define DPA_GNT_GROUPED(E)                                                                                          \
   if (epi == E) {                                                                                                   \
     static bool once = false;                                                                                       \
@@ -966,7 +966,7 @@ static void gemm_nt_launch(GemmNtArgs a, int epi, int num_cus, hipStream_t st) {
     hipLaunchKernelGGL((gemm_nt_kernel<E, false, 0, 0, true>), dim3(grid), dim3(512), kLds, st, a);                 \
     return;                                                                                                         \
   }
-    DPA_GNT_GROUPED(kEpiNone) DPA_GNT_GROUPED(kEpiGelu) DPA_GNT_GROUPED(kEpiMul)
+    DPA_GNT_GROUPED(kEpiNone) DPA_GNT_GROUPED(kEpiGelu) DPA_GNT_GROUPED(kEpiMul) DPA_GNT_GROUPED(kEpiSwiglu) DPA_GNT_GROUPED(kEpiDswiglu)
 #undef DPA_GNT_GROUPED
     return;
   }

@@ -162,7 +162,7 @@ struct GemmNtArgs {
   int skew_ticks;                                  // filled by gemm_nt() (benchmark knob)
   // Grouped mode (MoE experts): b is ignored; every 256-row block of a uses the weight matrix
   // w_ptrs[block_group[row / 256]] ([N, K], row stride ldb, all of one shape); a block whose group is outside
-  // [0, ngroups) multiplies by zeros. M must be a multiple of 256. Epilogues none / GELU / multiply only.
+  // [0, ngroups) multiplies by zeros. M must be a multiple of 256. Epilogues none / GELU / multiply / SwiGLU / dSwiGLU.
   const long long* w_ptrs;
   const int* block_group;
   int ngroups;

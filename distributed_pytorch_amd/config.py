@@ -173,6 +173,10 @@ PRESETS = {
     "gpt-moe-8x": dict(n_layer=12, n_embd=768, n_head=12, up_dim=3072, attn="mha", pos_emb="learn",
                        non_linearity="gelu", vocab_size=50304, block_size=1024, moe=True, n_exp=8, n_shared=0,
                        n_act=2, aux_free=False),
+    # the same with SwiGLU experts of 2/3 the width (equal parameter count): the reference's default activation
+    "gpt-moe-8x-swiglu": dict(n_layer=12, n_embd=768, n_head=12, up_dim=2048, attn="mha", pos_emb="learn",
+                              non_linearity="swiglu", vocab_size=50304, block_size=1024, moe=True, n_exp=8, n_shared=0,
+                              n_act=2, aux_free=False),
     # a LLaMA-style 124M: grouped-query attention (4 KV heads), rotary positions, SwiGLU with 2/3 of the width
     "gqa-rope-swiglu-124m": dict(n_layer=12, n_embd=768, n_head=12, n_kv_heads=4, up_dim=2048, attn="gqa", pos_emb="rope",
                                  non_linearity="swiglu", vocab_size=50304, block_size=1024),

@@ -290,18 +290,25 @@ class _GroupedExpertsFn(torch.autograd.Function):
         return (dx, dg, None, None, None, *g_fc, *g_proj)
 
 
+_EPI_GELU, _EPI_MUL, _EPI_SWIGLU, _EPI_DSWIGLU = 1, 2, 4, 5   # epilogues of the NT GEMM (csrc/kernels.h)
 NT_BLOCK = 256   # row-block size of the grouped mode of the NT GEMM (its output tile has 256 rows)
 
 
 def _nt_grouped_ok(x_flat, fc, proj, act: str, k: int = 8) -> bool:
-    """GELU experts on the grouped mode of the dense NT GEMM (csrc/gemm_nt.hip): same persistent 256 x 256
-    kernel as the dense layers, the weight matrix chosen per 256-row block, GELU / GELU' and the dGELU
-    multiply in its epilogues. Needs the 256-row layout."""
-    if act != "gelu" or os.environ.get("DPA_MOE_NT", "1") == "0":
+    """GELU or SwiGLU experts on the grouped mode of the dense NT GEMM (csrc/gemm_nt.hip): same persistent
+    256 x 256 kernel as the dense layers, the weight matrix chosen per 256-row block, GELU / GELU' and the
+    dGELU multiply, or SwiGLU and its backward, in its epilogues. Needs the 256-row layout."""
+    if act not in ("gelu", "swiglu") or os.environ.get("DPA_MOE_NT", "1") == "0":
+        return False
+    if act == "swiglu" and os.environ.get("DPA_MOE_NT_SWIGLU", "1") == "0":     # A/B switch
         return False
     if not (use_hip(x_flat) and x_flat.dtype == torch.bfloat16 and hasattr(ops(), "gemm_nt_grouped")):
         return False
     U, C = fc[0].shape
+    if act == "swiglu":
+        if U % 2:
+            return False
+        U //= 2
     return C % 64 == 0 and C >= 128 and U % 64 == 0 and U >= 128 and tuple(proj[0].shape) == (C, U)
 
 
@@ -309,49 +316,56 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
     """The routed experts of a layer as four grouped NT GEMMs and two grouped weight gradients."""
 
     @staticmethod
-    def forward(ctx, x_flat, gates, topk_indices, layout, *weights):
+    def forward(ctx, x_flat, gates, topk_indices, layout, act, *weights):
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         k = topk_indices.shape[1]
         row_of_pair, block_group, seg_start, seg_rows, rows = (layout or plan(topk_indices, E, NT_BLOCK))[:5]
         assert block_group.numel() * NT_BLOCK == rows, "the grouped NT GEMM needs the 256-row layout"
         xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows)
-        U, C = fc[0].shape
-        a, dact = ops().gemm_nt_grouped(xs, _ptr_table(fc), U, C, 1, None, block_group)
+        C = fc[0].shape[1]
+        U = proj[0].shape[1]
+        # GELU: a = gelu(h), side = gelu'(h); SwiGLU: a = silu(gate) * up, side = [gate | up]
+        a, side = ops().gemm_nt_grouped(xs, _ptr_table(fc), U, C, _EPI_SWIGLU if act == "swiglu" else _EPI_GELU, None,
+                                        block_group)
         y = ops().gemm_nt_grouped(a, _ptr_table(proj), C, U, 0, None, block_group)[0]
         gates_c = gates.contiguous()
         out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
-        ctx.save_for_backward(xs, a, dact, y, gates_c, row_of_pair, block_group, seg_start, seg_rows)
+        ctx.save_for_backward(xs, a, side, y, gates_c, row_of_pair, block_group, seg_start, seg_rows)
         ctx.params = weights
         ctx.k = k
+        ctx.act = act
         return out
 
     @staticmethod
     def backward(ctx, dout):
         from .linear import transposed_weight
-        xs, a, dact, y, gates, row_of_pair, block_group, seg_start, seg_rows = ctx.saved_tensors
+        xs, a, side, y, gates, row_of_pair, block_group, seg_start, seg_rows = ctx.saved_tensors
         weights = ctx.params
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
-        U, C = fc[0].shape
-        needs = ctx.needs_input_grad[4:]
+        W, C = fc[0].shape                 # W = U, or 2U with SwiGLU experts
+        U = proj[0].shape[1]
+        needs = ctx.needs_input_grad[5:]
         dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
         g_proj = [None] * E
         if any(needs[E:]):
             g_proj = _emit_wgrads(_grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
-        # dh = (dy W_proj) * gelu'(h): NT on the per-step cached transposes, the multiply in the epilogue
+        # dh = (dy W_proj) * gelu'(h), or the SwiGLU backward of it: NT on the per-step cached transposes, the
+        # activation's derivative in the epilogue
         proj_t = [transposed_weight(w) for w in proj]          # [U, C] each
-        dh = ops().gemm_nt_grouped(dy, _ptr_table(proj_t), U, C, 2, dact, block_group)[0]
+        dh = ops().gemm_nt_grouped(dy, _ptr_table(proj_t), U, C, _EPI_DSWIGLU if ctx.act == "swiglu" else _EPI_MUL, side,
+                                   block_group)[0]
         g_fc = [None] * E
         if any(needs[:E]):
             g_fc = _emit_wgrads(_grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
         dx = None
         if ctx.needs_input_grad[0]:
-            fc_t = [transposed_weight(w) for w in fc]          # [C, U] each
-            dxs = ops().gemm_nt_grouped(dh, _ptr_table(fc_t), C, U, 0, None, block_group)[0]
+            fc_t = [transposed_weight(w) for w in fc]          # [C, W] each
+            dxs = ops().gemm_nt_grouped(dh, _ptr_table(fc_t), C, W, 0, None, block_group)[0]
             dx = ops().moe_gather_combine(dxs, row_of_pair, None, ctx.k)
         dg = dgate.to(gates.dtype) if ctx.needs_input_grad[1] else None
-        return (dx, dg, None, None, *g_fc, *g_proj)
+        return (dx, dg, None, None, None, *g_fc, *g_proj)
 
 
 def grouped_layout_block(x_flat, fc_weights, proj_weights, act: str, k: int = 8) -> int:
@@ -382,7 +396,7 @@ def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, 
     assert len(fc_weights) == len(proj_weights)
     if _nt_grouped_ok(x_flat, fc_weights, proj_weights, act, topk_indices.shape[1]) and \
             (layout is None or layout[1].numel() * NT_BLOCK == layout[4]):
-        return _GroupedExpertsNtFn.apply(x_flat, topk_gates, topk_indices, layout, *fc_weights, *proj_weights)
+        return _GroupedExpertsNtFn.apply(x_flat, topk_gates, topk_indices, layout, act, *fc_weights, *proj_weights)
     if layout is not None and layout[1].numel() * BLOCK != layout[4]:
         layout = None      # made for the other kernels' block size
     return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, layout, *fc_weights, *proj_weights)
