@@ -1047,7 +1047,8 @@ bool decode_linear_supported(const Tensor& x, const Tensor& w, int64_t act, bool
 Tensor decode_linear(const Tensor& x, const std::optional<Tensor>& ln_w, const std::optional<Tensor>& ln_b, double eps,
                      const Tensor& w, const std::optional<Tensor>& bias, const std::optional<Tensor>& residual, int64_t act,
                      const std::optional<Tensor>& k_cache, const std::optional<Tensor>& v_cache,
-                     const std::optional<Tensor>& pos, int64_t kv_col0) {
+                     const std::optional<Tensor>& pos, int64_t kv_col0, const std::optional<Tensor>& rope_cos,
+                     const std::optional<Tensor>& rope_sin, int64_t rope_cols, int64_t rope_hs) {
   TORCH_CHECK(act >= 0 && act <= 2, "decode_linear: act 0 (none), 1 (GELU), 2 (SwiGLU)");
   TORCH_CHECK(decode_linear_supported(x, w, act, ln_w.has_value()),
               "decode_linear: unsupported operands (see decode_linear_supported)");
@@ -1101,6 +1102,21 @@ Tensor decode_linear(const Tensor& x, const std::optional<Tensor>& ln_w, const s
                 "decode_linear: residual is bf16 [B, N] with 8-byte aligned rows");
     p.residual = residual->data_ptr();
     p.ldr = residual->stride(0);
+  }
+  if (rope_cos.has_value()) {
+    auto row_ok = [&](const Tensor& t) {
+      return t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.numel() == rope_hs / 2 &&
+             reinterpret_cast<uintptr_t>(t.data_ptr()) % 8 == 0;
+    };
+    TORCH_CHECK(rope_sin.has_value() && row_ok(*rope_cos) && row_ok(*rope_sin),
+                "decode_linear: rope_cos / rope_sin are the fp32 [hs / 2] rows of the token's position");
+    TORCH_CHECK(act == dpa::kDecodeNone && !residual.has_value() && rope_hs >= 8 && rope_hs % 8 == 0 && rope_cols > 0 &&
+                    rope_cols % rope_hs == 0 && rope_cols <= N,
+                "decode_linear: the rotary epilogue takes whole heads of a plain projection");
+    p.rope_cos = rope_cos->data_ptr<float>();
+    p.rope_sin = rope_sin->data_ptr<float>();
+    p.rope_cols = (int)rope_cols;
+    p.rope_hs = (int)rope_hs;
   }
   p.y = y.data_ptr();
   p.ldy = y.stride(0);
@@ -1260,7 +1276,8 @@ TORCH_LIBRARY(dpa, m) {
         "Tensor(c!) dv, float scale, float p_drop=0.0, Tensor? seed=None, Tensor? rope_cos=None, Tensor? rope_sin=None, "
         "int rope_pos0=0) -> ()");
   m.def("decode_linear(Tensor x, Tensor? ln_w, Tensor? ln_b, float eps, Tensor w, Tensor? bias, Tensor? residual, int act, "
-        "Tensor(a!)? k_cache, Tensor(b!)? v_cache, Tensor? pos, int kv_col0) -> Tensor");
+        "Tensor(a!)? k_cache, Tensor(b!)? v_cache, Tensor? pos, int kv_col0, Tensor? rope_cos=None, Tensor? rope_sin=None, "
+        "int rope_cols=0, int rope_hs=0) -> Tensor");
   m.def("decode_linear_supported(Tensor x, Tensor w, int act, bool has_ln) -> bool");
   m.def("gemm_nt_rope(Tensor a, Tensor b, Tensor? bias, Tensor rope_cos, Tensor rope_sin, int pos0, int seq_len, "
         "int rope_cols, int hs) -> Tensor");

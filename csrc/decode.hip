@@ -7,7 +7,7 @@
 // library GEMM with 16 x 16 tiles, activation, add) a 124M-parameter model takes ~10 launches of 4-12 us
 // per layer; the weights of a whole layer stream from HBM in 3 us. Here the LayerNorm is the prologue
 // (every workgroup normalises the <= 16 rows itself: 12 KB from L2), bias / exact-erf GELU / SwiGLU /
-// residual are the epilogue, and the key / value columns of a fused qkv projection can be written
+// residual (and the rotary embedding of a qkv projection's query / key heads) are the epilogue, and the key / value columns of a fused qkv projection can be written
 // straight into the preallocated KV cache at the device-side position, so a dense block is five launches.
 //
 // Structure: one 256-thread workgroup per 16 output features and group of 16 rows (blockIdx.y; the groups of a
@@ -88,6 +88,14 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
     }
     if (p.residual != nullptr && l15 < B)
       rr = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.residual) + (long long)(row0 + l15) * p.ldr + n);
+  }
+  // rotary pairs (n, n + 1) and (n + 2, n + 3) of a head: angles (n % hs) / 2 and the next
+  const bool rot = ACT == kDecodeNone && p.rope_cos != nullptr && n < p.rope_cols;
+  f32x2 rc = {1.f, 1.f}, rs = {0.f, 0.f};
+  if (wave == 0 && rot) {
+    const int pi = (n % p.rope_hs) >> 1;
+    rc = *reinterpret_cast<const f32x2*>(p.rope_cos + pi);
+    rs = *reinterpret_cast<const f32x2*>(p.rope_sin + pi);
   }
 
   // ---- stage the activations: LayerNorm (fp32 statistics, two passes over registers) or a copy (rows past B are not staged) ----
@@ -219,6 +227,13 @@ __global__ __launch_bounds__(NW * 64) void decode_linear_kernel(DecodeLinearArgs
   for (int r = 0; r < 4; ++r) {
     if (ACT == kDecodeGelu) v[r] = gelu_erf(v[r]);
     if (kPair) v[r] = v[r] / (1.0f + __expf(-v[r])) * v2[r];
+  }
+  if (rot) {
+    const float e0 = v[0], o0 = v[1], e1 = v[2], o1 = v[3];
+    v[0] = e0 * rc[0] - o0 * rs[0];
+    v[1] = e0 * rs[0] + o0 * rc[0];
+    v[2] = e1 * rc[1] - o1 * rs[1];
+    v[3] = e1 * rs[1] + o1 * rc[1];
   }
   v[0] += lo_bf16(rr[0]);
   v[1] += hi_bf16(rr[0]);

@@ -211,6 +211,11 @@ struct DecodeLinearArgs {
   long long cache_bs;
   const long long* pos;
   int kv_col0, kv_cols;
+  // rotary embedding of the output columns below rope_cols (heads of rope_hs columns, interleaved pairs), applied to
+  // the fp32 result before rounding: rope_cos / rope_sin = the fp32 [rope_hs / 2] rows of the token's position
+  // (nullptr: none). act must be kDecodeNone, rope_cols % rope_hs == 0.
+  const float *rope_cos, *rope_sin;
+  int rope_cols, rope_hs;
 };
 bool decode_linear_ok(long long B, long long N, long long K, long long ldx, long long ldw, bool pair, bool has_ln);
 void decode_linear(const DecodeLinearArgs& p, hipStream_t st);

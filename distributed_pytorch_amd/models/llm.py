@@ -563,15 +563,11 @@ class Block(nn.Module):
         if delta is not None:
             x2 = x2 + delta.reshape(B, C)
         ln1 = (self.ln1.weight, self.ln1.bias, self.ln1.eps)
-        if rope is None:
-            # LayerNorm + qkv projection + bias; the new key / value rows land in the cache at the device position
-            q = ops.decode_linear(x2, ln1, a.c_attn.weight, a.c_attn.bias, kv=(cache.k, cache.v, cache.pos, nh * hs))
-            q = q.view(B, 1, nh, hs)
-        else:
-            qkv = ops.decode_linear(x2, ln1, a.c_attn.weight, a.c_attn.bias).view(B, 1, -1)
-            qkv = ops.rope_qkv_(qkv, rope[0], rope[1], rope[2], nh + nkv, hs)
-            q, k, v = ops.split_qkv(qkv, nh, nkv)
-            ops.kv_append(cache.k, cache.v, k, v, cache.pos)
+        # LayerNorm + qkv projection + bias (+ the rotation of the query and key heads: `rope` holds the angle rows of
+        # this position); the new key / value rows land in the cache at the device position
+        rot = None if rope is None else (rope[0].reshape(-1), rope[1].reshape(-1), (nh + nkv) * hs, hs)
+        q = ops.decode_linear(x2, ln1, a.c_attn.weight, a.c_attn.bias, kv=(cache.k, cache.v, cache.pos, nh * hs), rope=rot)
+        q = q.view(B, 1, nh, hs)
         y = ops.cached_attention(q, cache.k, cache.v, cache.len_after)
         x2 = ops.decode_linear(y.reshape(B, C), None, a.c_proj.weight, a.c_proj.bias, residual=x2)
         act = ops.ACT_SWIGLU if m.non_linearity == "swiglu" else ops.ACT_GELU

@@ -46,12 +46,14 @@ def decode_linear_eager(x2, ln, w, bias, residual, act):
 
 
 def decode_linear(x2: torch.Tensor, ln, w: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE,
-                  kv=None) -> torch.Tensor:
+                  kv=None, rope=None) -> torch.Tensor:
     """``ln``: ``(weight, bias | None, eps)`` or None. ``kv``: ``(k_cache, v_cache, pos, kv_col0)``: the
     output columns from ``kv_col0`` on are appended to the caches at row ``pos`` (int64 ``[1]`` on the
-    device) and only the columns below ``kv_col0`` are returned. No gradient."""
+    device) and only the columns below ``kv_col0`` are returned. ``rope``: ``(cos_row, sin_row, rope_cols,
+    hs)``: the heads (``hs`` columns each) below column ``rope_cols`` are rotated by the fp32 ``[hs / 2]``
+    angle rows of the token's position before anything is stored. No gradient."""
     lw, lb, eps = (ln[0], ln[1], float(ln[2])) if ln is not None else (None, None, 0.0)
-    if kv is None:
-        return ops().decode_linear(x2, lw, lb, eps, w, bias, residual, int(act), None, None, None, 0)
-    k_cache, v_cache, pos, col0 = kv
-    return ops().decode_linear(x2, lw, lb, eps, w, bias, residual, int(act), k_cache, v_cache, pos, int(col0))
+    k_cache, v_cache, pos, col0 = kv if kv is not None else (None, None, None, 0)
+    rc, rs, rcols, hs = rope if rope is not None else (None, None, 0, 0)
+    return ops().decode_linear(x2, lw, lb, eps, w, bias, residual, int(act), k_cache, v_cache, pos, int(col0),
+                               rc, rs, int(rcols), int(hs))

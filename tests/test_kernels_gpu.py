@@ -1214,6 +1214,35 @@ def test_decode_linear_writes_new_key_value_rows_into_the_cache(batch):
     assert torch.equal(kc[:, keep], k0[:, keep]) and torch.equal(vc[:, keep], v0[:, keep])   # nothing else is touched
 
 
+@pytest.mark.parametrize("batch,hs", [(3, 64), (20, 128)])
+def test_decode_linear_rotates_query_and_key_heads(batch, hs):
+    """The rotary epilogue of the decode-step qkv projection: query columns returned rotated, key rows cached rotated,
+    value rows untouched, against the plain projection followed by the fp32 rotation."""
+    from distributed_pytorch_amd import ops
+    from distributed_pytorch_amd.ops.rope import rope_tables
+    torch.manual_seed(2)
+    B, S, nh, nkv, K = batch, 16, 4, 2, 512
+    W = (nh + 2 * nkv) * hs
+    x = torch.randn(B, K, device="cuda").bfloat16()
+    w = (torch.randn(W, K, device="cuda") / math.sqrt(K)).bfloat16()
+    bias = (torch.randn(W, device="cuda") * 0.1).bfloat16()
+    lnp = ((torch.randn(K, device="cuda") * 0.2 + 1).bfloat16(), (torch.randn(K, device="cuda") * 0.1).bfloat16(), 1e-5)
+    cos_t, sin_t = rope_tables(64, hs, device="cuda")
+    p = 11
+    kc = torch.zeros(B, S, nkv, hs, device="cuda").bfloat16()
+    vc = torch.zeros_like(kc)
+    pos = torch.tensor([5], dtype=torch.int64, device="cuda")
+    q = ops.decode_linear(x, lnp, w, bias, kv=(kc, vc, pos, nh * hs), rope=(cos_t[p].contiguous(), sin_t[p].contiguous(), (nh + nkv) * hs, hs))
+    full = ops.decode_linear_eager(x.float(), (lnp[0].float(), lnp[1].float(), 1e-5), w.float(), bias.float(), None, ops.ACT_NONE)
+    qk = full[:, : (nh + nkv) * hs].view(B, nh + nkv, hs // 2, 2)
+    c, s_ = cos_t[p].view(1, 1, -1), sin_t[p].view(1, 1, -1)
+    rot = torch.stack((qk[..., 0] * c - qk[..., 1] * s_, qk[..., 0] * s_ + qk[..., 1] * c), dim=-1).view(B, -1)
+    assert torch.allclose(q.float(), rot[:, : nh * hs], atol=4e-2, rtol=3e-2)
+    assert torch.allclose(kc[:, 5].reshape(B, -1).float(), rot[:, nh * hs:], atol=4e-2, rtol=3e-2)
+    assert torch.allclose(vc[:, 5].reshape(B, -1).float(), full[:, (nh + nkv) * hs:], atol=4e-2, rtol=3e-2)
+    assert rel_err(q, rot[:, : nh * hs]) < 1e-2 and rel_err(kc[:, 5].reshape(B, -1), rot[:, nh * hs:]) < 1e-2
+
+
 def test_sampler_step_form_records_the_token_and_advances_the_counters():
     """The decode-step form of the sampler: tokens into the next input and the history column, device counters
     advanced once per launch by the last workgroup, top-1 equal to argmax, draws that change with the position."""
