@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+# the tests drive the own NT GEMM at shapes far below the size from which the dispatch prefers it over the library
+os.environ.setdefault("DPA_GEMM_MIN_TILES", "0")
 
 REFERENCE_ROOT = "/root/reference"
 

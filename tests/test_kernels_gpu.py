@@ -868,6 +868,21 @@ def test_gemm_nt_rows_past_two_gib_run_as_row_ranges():
     assert (dh[rows][:, U:].float() - v * g * sg).abs().max() <= 2e-2 * (v * g).abs().max() + 1e-3
 
 
+def test_small_products_go_to_the_library(monkeypatch):
+    """Dispatch rule: below half a round of 256 x 256 output tiles the library serves the product (same result)."""
+    import importlib
+    L = importlib.import_module("distributed_pytorch_amd.ops.linear")
+    a = torch.randn(4096, 768, device=DEV).bfloat16()
+    w_small = (torch.randn(768, 768, device=DEV) * 0.05).bfloat16()      # 16 x 3 tiles
+    w_large = (torch.randn(3072, 768, device=DEV) * 0.05).bfloat16()     # 16 x 12 tiles
+    monkeypatch.setattr(L, "GEMM_MIN_TILES", 128)
+    assert not L.gemm_supported(a, w_small) and L.gemm_supported(a, w_large)
+    y_lib = L.linear(a, w_small)
+    monkeypatch.setattr(L, "GEMM_MIN_TILES", 0)
+    assert L.gemm_supported(a, w_small)
+    assert rel_err(L.linear(a, w_small), y_lib.float()) < 4e-3
+
+
 def test_transpose_bf16():
     x = torch.randn(3072, 768, device=DEV).bfloat16()
     assert torch.equal(_ops().transpose_bf16(x), x.t().contiguous())
