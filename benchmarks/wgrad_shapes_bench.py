@@ -18,6 +18,9 @@ def timeit(fn, n=12):
     return ts[len(ts) // 2]
 
 CASES = {
+    "124m, micro-batch 4": (4096, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+    "124m, micro-batch 8": (8192, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+    "124m, micro-batch 16": (16384, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
     "124m": (65536, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
     "350m": (32768, [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]),
     "1.3b": (16384, [(6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192)]),
