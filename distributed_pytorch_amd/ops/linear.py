@@ -229,7 +229,9 @@ class _LinearFn(torch.autograd.Function):
             # _unsafe_view: the freshly made GEMM output reshaped WITHOUT view tracking, so that the caller
             # may update it in place (rotary embedding of the q / k columns) like any tensor it owns
             return torch.ops.aten._unsafe_view(ops().gemm_nt(x2, w, b, _EPI_NONE, None)[0], (*x.shape[:-1], w.shape[0]))
-        return F.linear(x, w, b)
+        # library product on the 2-D rows, reshaped the same way (F.linear on a 3-D input hands back a tracked view,
+        # which a custom Function's output must not be if the caller is to update it in place)
+        return torch.ops.aten._unsafe_view(F.linear(x2, w, b), (*x.shape[:-1], w.shape[0]))
 
     @staticmethod
     def backward(ctx, dy):

@@ -244,3 +244,19 @@ def test_graphed_decode_batch_sizes_around_the_fused_kernels_limit(batch):
     assert (graphed == eager).float().mean().item() > 0.97
     x = torch.randn(batch, 1, cfg.n_embd, device="cuda").bfloat16()
     assert model.transformer.h[0]._decode_ok(x) == (batch <= 64)
+
+
+def test_rope_block_trains_when_the_projection_runs_on_the_library(monkeypatch):
+    """A rotary model whose qkv projection is below the own GEMM's dispatch bar: the library product's output is
+    rotated in place like the own kernel's (it must not be a tracked view of a custom Function's result)."""
+    import importlib
+    L = importlib.import_module("distributed_pytorch_amd.ops.linear")
+    monkeypatch.setattr(L, "GEMM_MIN_TILES", 1 << 20)          # every product to the library
+    torch.manual_seed(0)
+    cfg = LLMconfig(**{**BASE, **VARIANTS["gqa_rope_swiglu"]}).finalize()
+    model = LLM(cfg).to("cuda").to(torch.bfloat16)
+    idx = torch.randint(0, cfg.vocab_size, (4, cfg.block_size), device="cuda")
+    _, loss, _ = model(idx, idx)
+    loss.backward()
+    g = model.transformer.h[0].attn.attn.c_attn.weight.grad
+    assert torch.isfinite(loss) and g is not None and torch.isfinite(g).all() and g.abs().max() > 0
