@@ -1241,6 +1241,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
   m.def("wgrad2(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_set_stages(int s) -> ()");
+  m.def("clear_last_error() -> int");
   m.def("wgrad2_slabs(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_accum(Tensor dy, Tensor x, Tensor(a!) ws) -> ()");
   m.def("layernorm_fwd(Tensor x, Tensor? res, Tensor w, Tensor b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
@@ -1286,6 +1287,9 @@ TORCH_LIBRARY(dpa, m) {
 
 TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
   m.impl("wgrad2_set_stages", [](int64_t s) { dpa::wgrad2_set_stages((int)s); });
+  // Reads and clears the runtime's sticky "last error" of this thread (a stream capture that was invalidated leaves
+  // one behind, and the next launch's error check would report it as its own). Returns the error code read.
+  m.impl("clear_last_error", []() -> int64_t { return (int64_t)hipGetLastError(); });
   m.impl("gemm_nt_set_variant", [](int64_t v) { dpa::gemm_nt_set_variant((int)v); });
   m.impl("grouped_wgrad_use_wgrad3", [](bool on, bool any_size) { grouped_wgrad_use_wgrad3(on, any_size); });
   m.impl("gemm_nt_supported", gemm_nt_supported);

@@ -123,6 +123,12 @@ def transposed_weight(w: torch.Tensor) -> torch.Tensor:
     """``w.T`` as a contiguous bf16 matrix, cached per weight version (recomputed inside a hipGraph
     capture, where the replay has to redo it)."""
     if torch.cuda.is_current_stream_capturing():
+        # the warm-up steps left a buffer for this weight: refill it, so that its address (which grouped products
+        # keep in cached pointer tables) is the same in every replay and outside the graph's own pool
+        ent = _WT_CACHE.get(id(w))
+        if ent is not None and ent[2]() is w and ent[1].shape == (w.shape[1], w.shape[0]):
+            ent[1].copy_(w.detach().t())
+            return ent[1]
         return ops().transpose_bf16(w.detach())
     # Keyed by the weight tensor itself, not by its address: engines that gather parameters into
     # recycled buffers (fully sharded units) put different weights of equal shape at the same address.

@@ -28,6 +28,24 @@ import math
 import torch
 
 
+def _clear_runtime_error() -> None:
+    """An invalidated capture leaves the runtime's sticky last-error set; the next launch's error check would
+    report it as its own failure. Read it away (and drop what the failed capture left in the allocator)."""
+    try:
+        from .._ext import ops as _ops
+        _ops().clear_last_error()
+    except Exception:
+        pass
+    try:
+        torch.cuda.synchronize()
+    except Exception:
+        try:
+            from .._ext import ops as _ops
+            _ops().clear_last_error()
+        except Exception:
+            pass
+
+
 class GraphedTrainStep:
     """``step(batches, lr) -> loss`` where ``batches`` is a list of ``accum`` ``(x, y)`` pairs of shape
     ``[B, T]``. The first ``warmup`` calls run eagerly (they are real training steps and let every
@@ -99,6 +117,7 @@ class GraphedTrainStep:
                     eng.step_count = count
                     self.failed = True
                     self.x = self.y = self.loss = None
+                    _clear_runtime_error()
                     torch.cuda.synchronize()
                     print(f"[hip_graph] capture failed ({type(exc).__name__}: {exc}); continuing eagerly", flush=True)
                     self._set_scalars(lr)

@@ -1,5 +1,6 @@
 """End-to-end checks on the MI355X: the bf16 HIP path against the fp32 eager path of the same
 model, every engine type stepping on the GPU, and the HIP extension actually being used."""
+import math
 import os
 
 import pytest
@@ -164,6 +165,47 @@ def test_graphed_step_with_dropout_captures_and_redraws_masks():
     losses = [gs.step([(x, x.roll(-1, 1))], 0.0).item() for _ in range(5)]
     assert gs.graph is not None and not gs.failed
     assert len({round(v, 6) for v in losses[2:]}) > 1, losses   # lr = 0: only the masks change
+
+
+def test_graphed_step_falls_back_to_eager_when_the_capture_fails():
+    """A step that cannot be captured (here: a host read in the middle of it) is reported once and training
+    continues eagerly, with the runtime's sticky capture error cleared."""
+    from distributed_pytorch_amd.parallel.engine import Engine
+    from distributed_pytorch_amd.parallel.graph import GraphedTrainStep
+    cfg = LLMconfig(**{**BASE, **VARIANTS["gpt2"]}).finalize()
+    torch.manual_seed(3)
+    eng = Engine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3)
+    eng.train()
+    gs = GraphedTrainStep(eng, accum=1, grad_clip=1.0, warmup=1)
+    body = gs._body
+
+    def body_with_host_read(xs, ys):
+        loss = body(xs, ys)
+        if torch.cuda.is_current_stream_capturing():
+            loss.item()                       # a synchronising read: not allowed while capturing
+        return loss
+    gs._body = body_with_host_read
+    x = torch.randint(0, cfg.vocab_size, (4, 256), device="cuda")
+    losses = [gs.step([(x, x.roll(-1, 1))], 1e-3).item() for _ in range(5)]
+    assert gs.failed and gs.graph is None
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0]
+
+
+def test_graphed_step_captures_moe_with_swiglu_experts():
+    """Experts on the grouped NT GEMM under hipGraph capture: the per-step transposed weights keep the addresses of
+    the warm-up steps, so the cached pointer tables stay valid and nothing is copied from the host while capturing."""
+    from distributed_pytorch_amd.parallel.engine import Engine
+    from distributed_pytorch_amd.parallel.graph import GraphedTrainStep
+    cfg = LLMconfig(**{**BASE, "attn": "mha", "pos_emb": "learn", "non_linearity": "swiglu", "moe": True, "n_exp": 4,
+                       "n_shared": 1, "n_act": 2}).finalize()
+    torch.manual_seed(4)
+    eng = Engine(LLM(cfg), dtype="bf16", device="cuda:0", lr=1e-3)
+    eng.train()
+    gs = GraphedTrainStep(eng, accum=1, grad_clip=1.0, warmup=2)
+    x = torch.randint(0, cfg.vocab_size, (4, 256), device="cuda")
+    losses = [gs.step([(x, x.roll(-1, 1))], 1e-3).item() for _ in range(8)]
+    assert gs.graph is not None and not gs.failed
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0]
 
 
 def test_trainer_resume_on_gpu(tmp_path):
