@@ -180,11 +180,25 @@ def _ptr_table(ws) -> torch.Tensor:
 
 
 def _act_fwd(h, act):
-    return ops().swiglu_fwd(h) if act == "swiglu" else ops().gelu_fwd(h)
+    if act == "swiglu":
+        return ops().swiglu_fwd(h)
+    if act == "gelu":
+        return ops().gelu_fwd(h)
+    from .activation import get_activation     # the other elementwise activations of the reference's table
+    with torch.no_grad():
+        return get_activation(act)(h)
 
 
 def _act_bwd(da, h, act):
-    return ops().swiglu_bwd(da, h) if act == "swiglu" else ops().gelu_bwd(da, h)
+    if act == "swiglu":
+        return ops().swiglu_bwd(da, h)
+    if act == "gelu":
+        return ops().gelu_bwd(da, h)
+    from .activation import get_activation
+    with torch.enable_grad():
+        hh = h.detach().requires_grad_()
+        a = get_activation(act)(hh)
+    return torch.autograd.grad(a, hh, da)[0]
 
 
 def _direct_grad(p):
@@ -375,7 +389,7 @@ def grouped_layout_block(x_flat, fc_weights, proj_weights, act: str, k: int = 8)
 
 
 def grouped_supported(x_flat, fc_weights, proj_weights, act: str) -> bool:
-    if act not in ("gelu", "swiglu") or not use_hip(x_flat) or x_flat.dtype != torch.bfloat16:
+    if act == "glu" or not use_hip(x_flat) or x_flat.dtype != torch.bfloat16:     # glu halves the width
         return False
     if os.environ.get("DPA_MOE_GROUPED", "1") == "0":   # A/B switch: per-expert library GEMMs
         return False
@@ -391,7 +405,7 @@ def grouped_supported(x_flat, fc_weights, proj_weights, act: str) -> bool:
 
 def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str, layout=None) -> torch.Tensor:
     """sum_s gate[t, s] * expert_{idx[t, s]}(x[t]) for bias-free two-layer experts
-    (``act`` = "gelu" or "swiglu") on the grouped HIP kernels. ``layout`` = a ``plan()`` result for
+    (``act`` = "swiglu" or an elementwise activation of the reference's table) on the grouped HIP kernels. ``layout`` = a ``plan()`` result for
     ``topk_indices`` if the caller already has one."""
     assert len(fc_weights) == len(proj_weights)
     if _nt_grouped_ok(x_flat, fc_weights, proj_weights, act, topk_indices.shape[1]) and \
@@ -410,8 +424,11 @@ def grouped_experts_eager(x_flat, topk_indices, topk_gates, fc_weights, proj_wei
         if act == "swiglu":
             u, v = h.chunk(2, dim=-1)
             a = F.silu(u) * v
-        else:
+        elif act == "gelu":
             a = F.gelu(h)
+        else:
+            from .activation import _KINDS
+            a = _KINDS[act][1](h)
         y = F.linear(a, wp)
         w = (topk_gates * (topk_indices == e)).sum(1, keepdim=True)
         out = out + w.to(y.dtype) * y

@@ -400,7 +400,8 @@ def test_grouped_wgrad_segments():
 
 @pytest.mark.parametrize("nt", ["1", "0"])
 @pytest.mark.parametrize("act,E,k,Ntok,C,U", [("gelu", 8, 2, 4096, 768, 3072), ("swiglu", 3, 2, 1000, 256, 384),
-                                              ("gelu", 4, 1, 77, 128, 128), ("swiglu", 8, 2, 4096, 768, 2048)])
+                                              ("gelu", 4, 1, 77, 128, 128), ("swiglu", 8, 2, 4096, 768, 2048),
+                                              ("relu", 4, 2, 1000, 256, 384), ("silu", 3, 1, 300, 128, 256)])
 def test_grouped_experts_fwd_bwd(act, E, k, Ntok, C, U, nt, monkeypatch):
     # nt = "1": the experts on the grouped mode of the NT GEMM (256-row blocks); "0": the 128-row grouped kernels
     monkeypatch.setenv("DPA_MOE_NT", nt)
