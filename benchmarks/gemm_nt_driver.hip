@@ -1,6 +1,8 @@
 // Stand-alone check + timing of csrc/gemm_nt.hip (no PyTorch): every epilogue against a plain fp32
 // reference kernel on random operands, then TFLOP/s on the GPT-2 layer shapes.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Icsrc benchmarks/gemm_nt_driver.hip csrc/gemm_nt.hip -o benchmarks/gemm_nt_driver.bin
+// With -DDPA_WITH_FORM2 and benchmarks/experiments/gemm_nt2.hip on the command line, the modes check2 / ab / skew2 and
+// DPA_FORM=2 also run the two-workgroups-per-CU experiment (measured slower, kept for the record).
 //   ./benchmarks/gemm_nt_driver.bin [check|bench|all]
 #include <hip/hip_runtime.h>
 
@@ -12,6 +14,14 @@
 #include <vector>
 
 #include "kernels.h"
+
+#ifdef DPA_WITH_FORM2
+namespace dpa {
+bool gemm_nt2_ok(int epi, bool grouped);
+void gemm_nt2(GemmNtArgs a, int epi, int num_cus, hipStream_t st);
+void gemm_nt2_set_skew(int ticks);
+}
+#endif
 
 #define CK(x)                                                                        \
   do {                                                                               \
@@ -67,6 +77,16 @@ __global__ void ref_kernel(const bf16* a, const bf16* b, const bf16* bias, const
 }
 
 static int g_cus = 256;
+static int g_form = 1;   // 1: gemm_nt (one workgroup per CU), 2: gemm_nt2 (two per CU)
+static void run_gemm(const dpa::GemmNtArgs& g, int epi) {
+#ifdef DPA_WITH_FORM2
+  if (g_form == 2) {
+    dpa::gemm_nt2(g, epi, g_cus, 0);
+    return;
+  }
+#endif
+  dpa::gemm_nt(g, epi, g_cus, 0);
+}
 
 #ifdef DPA_GEMM_TRACE
 namespace dpa { void gemm_nt_read_trace(unsigned long long* out); }
@@ -132,7 +152,7 @@ static double run_case(int M, int N, int K, int epi, bool bias, bool check, int 
     CK(hipMalloc(&ra, (long long)nrows * N * 4));
     ref_kernel<<<dim3((N + 127) / 128, nrows), 128>>>(a, b, bias ? bv : nullptr, aux, ro, ra, M, N, K, K, K, N, epi, row_step);
     CK(hipDeviceSynchronize());
-    dpa::gemm_nt(g, epi, g_cus, 0);
+    run_gemm(g, epi);
     CK(hipDeviceSynchronize());
     std::vector<float> hro((size_t)nrows * N), hra((size_t)nrows * N);
     std::vector<bf16> hc((size_t)nc), hx;
@@ -171,7 +191,7 @@ static double run_case(int M, int N, int K, int epi, bool bias, bool check, int 
         }
       }
     }
-    printf("check M=%d N=%d K=%d epi=%d bias=%d: worst rel err %.3e, %lld bad of %lld  %s\n", M, N, K, epi, (int)bias,
+    printf("check form %d M=%d N=%d K=%d epi=%d bias=%d: worst rel err %.3e, %lld bad of %lld  %s\n", g_form, M, N, K, epi, (int)bias,
            worst, bad, (long long)nrows * N, bad ? "FAIL" : "ok");
     fflush(stdout);
     CK(hipFree(ro));
@@ -183,12 +203,12 @@ static double run_case(int M, int N, int K, int epi, bool bias, bool check, int 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) dpa::gemm_nt(g, epi, g_cus, 0);
+    for (int i = 0; i < 3; ++i) run_gemm(g, epi);
     CK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int i = 0; i < iters; ++i) {
       CK(hipEventRecord(e0, 0));
-      dpa::gemm_nt(g, epi, g_cus, 0);
+      run_gemm(g, epi);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -198,7 +218,7 @@ static double run_case(int M, int N, int K, int epi, bool bias, bool check, int 
     std::sort(ts.begin(), ts.end());
     const float med = ts[ts.size() / 2];
     tf = 2.0 * M * N * K / (med * 1e-3) / 1e12;
-    printf("bench M=%d N=%d K=%d epi=%d bias=%d: median %.1f us (min %.1f)  %.1f TF\n", M, N, K, epi, (int)bias,
+    printf("bench form %d M=%d N=%d K=%d epi=%d bias=%d: median %.1f us (min %.1f)  %.1f TF\n", g_form, M, N, K, epi, (int)bias,
            med * 1e3, ts[0] * 1e3, tf);
     fflush(stdout);
   }
@@ -212,6 +232,7 @@ int main(int argc, char** argv) {
   CK(hipGetDeviceProperties(&prop, 0));
   g_cus = prop.multiProcessorCount;
   printf("device %s, %d CUs\n", prop.name, g_cus);
+  if (getenv("DPA_FORM")) g_form = atoi(getenv("DPA_FORM"));   // 2: the two-workgroups-per-CU kernel in every mode
   if (!strcmp(mode, "check") || !strcmp(mode, "all")) {
     run_case(256, 256, 128, 0, false, true, 0);
     run_case(512, 512, 192, 0, false, true, 0);
@@ -225,6 +246,59 @@ int main(int argc, char** argv) {
     run_case(2100, 768, 256, 3, true, true, 0);
     run_case(8192, 50304, 768, 0, false, true, 0);   // lm_head chunk: column tail, tiles_n = 197
   }
+  if (!strcmp(mode, "check2")) {   // the two-workgroups-per-CU form against the reference
+    g_form = 2;
+    run_case(128, 256, 128, 0, false, true, 0);
+    run_case(256, 256, 192, 0, false, true, 0);
+    run_case(512, 512, 192, 0, false, true, 0);
+    run_case(1000, 752, 192, 0, true, true, 0);      // row and column tails
+    run_case(3000, 1040, 320, 0, false, true, 0);
+    run_case(40000, 2304, 768, 0, true, true, 0);    // persistent path: many tiles per workgroup, row tail
+    run_case(2048, 768, 256, 1, false, true, 0);
+    run_case(33000, 3072, 768, 1, false, true, 0);
+    run_case(2048, 768, 256, 2, true, true, 0);
+    run_case(33000, 3072, 768, 2, false, true, 0);
+    run_case(2100, 768, 256, 3, true, true, 0);
+    run_case(33000, 768, 3072, 3, false, true, 0);
+    run_case(8192, 50304, 768, 0, false, true, 0);   // lm_head chunk: column tail, tiles_n = 197
+    run_case(4096, 768, 50304, 0, false, true, 0);   // lm_head dx: long K
+    run_case(6000, 2048, 1024, 0, false, true, 0);   // nk = 16: not a multiple of the ring's period
+  }
+  if (!strcmp(mode, "ab")) {   // both forms, interleaved, on the layer shapes (M = argv[2], default 65536)
+    const int M = argc > 2 ? atoi(argv[2]) : 65536;
+    struct S { int N, K, epi; bool bias; };
+    const S shapes[] = {{2304, 768, 0, true}, {768, 768, 3, true}, {3072, 768, 0, false}, {3072, 768, 1, false}, {3072, 768, 2, false},
+                        {768, 3072, 3, false}, {768, 3072, 0, false}, {768, 2304, 0, false}, {768, 768, 0, false}};
+    for (int rep = 0; rep < 2; ++rep)
+      for (const S& s : shapes)
+        for (int f : {1, 2}) {
+          g_form = f;
+          run_case(M, s.N, s.K, s.epi, s.bias, false, 20);
+        }
+    for (int f : {1, 2}) {
+      g_form = f;
+      run_case(16384, 50304, 768, 0, false, false, 10);
+      run_case(16384, 768, 50304, 0, false, false, 10);
+      run_case(4096, 4096, 4096, 0, false, false, 20);
+      run_case(8192, 8192, 8192, 0, false, false, 10);
+    }
+    g_form = 1;
+  }
+#ifdef DPA_WITH_FORM2
+  if (!strcmp(mode, "skew2")) {   // start skew of the second workgroup of each CU (10 ns ticks)
+    g_form = 2;
+    for (int ticks : {0, 300, 600, 1000, 1500, -1}) {
+      printf("---- skew %d ticks\n", ticks);
+      dpa::gemm_nt2_set_skew(ticks);
+      run_case(65536, 3072, 768, 1, false, false, 20);
+      run_case(65536, 3072, 768, 2, false, false, 20);
+      run_case(65536, 3072, 768, 0, false, false, 20);
+      run_case(65536, 768, 3072, 3, false, false, 20);
+    }
+    dpa::gemm_nt2_set_skew(-1);
+    g_form = 1;
+  }
+#endif
   if (!strcmp(mode, "variants")) {
     const int M = 65536;
     for (int v : {0, 1, 2, 3}) {

@@ -24,6 +24,8 @@ struct TileCoord {
 // tile bijection is correct; this one is for locality.
 struct GemmWalk {
   int tiles_m, tiles_n, nwg;
+  int tile_h = 256;   // rows of an output tile (columns are always 256): 128 for the two-workgroups-per-CU kernel
+  int group_m = 4;    // m-tiles of a block of tiles that run at the same time on one XCD
   DPA_HD bool xcd_mode() const { return tiles_m >= 8 && (nwg & 7) == 0; }
   DPA_HD int count(int wg) const {
     if (!xcd_mode()) {
@@ -39,31 +41,31 @@ struct GemmWalk {
     TileCoord t;
     if (!xcd_mode()) {
       const int s = wg + it * nwg;
-      t.m0 = (s % tiles_m) * 256;
+      t.m0 = (s % tiles_m) * tile_h;
       t.n0 = (s / tiles_m) * 256;
       return t;
     }
     const int x = wg & 7, slot = wg >> 3, per = nwg >> 3;
     const int lo = x * tiles_m / 8, hi = (x + 1) * tiles_m / 8;
     const int s = slot + it * per;
-    const int gsz = 4 * tiles_n;
-    const int nfull = (hi - lo) / 4;
-    int g = s / gsz, r = s % gsz, gm = 4;
+    const int gsz = group_m * tiles_n;
+    const int nfull = (hi - lo) / group_m;
+    int g = s / gsz, r = s % gsz, gm = group_m;
     if (g >= nfull) {
       g = nfull;
       r = s - nfull * gsz;
-      gm = (hi - lo) - 4 * nfull;
+      gm = (hi - lo) - group_m * nfull;
     }
     t.n0 = (r / gm) * 256;
-    t.m0 = (lo + 4 * g + r % gm) * 256;
+    t.m0 = (lo + group_m * g + r % gm) * tile_h;
     return t;
   }
 };
 
 // Number of workgroups the NT GEMM launches for a tile grid on a part with `num_cus` compute units.
-inline int gemm_nt_grid(int tiles_m, int tiles_n, int num_cus) {
+inline int gemm_nt_grid(int tiles_m, int tiles_n, int num_cus, int wg_per_cu = 1) {
   const int total = tiles_m * tiles_n;
-  int grid = num_cus > 0 ? num_cus : 256;
+  int grid = (num_cus > 0 ? num_cus : 256) * wg_per_cu;
   grid &= ~7;
   if (grid < 8) grid = 8;
   if (tiles_m < 8 && grid > total) grid = total;

@@ -89,13 +89,16 @@ static void test_token_stream(const std::string& dir) {
 }
 
 static void test_gemm_walk() {
-  // every (workgroup, iteration) pair maps to a distinct tile inside the grid and all tiles are covered
-  for (int tm : {1, 2, 3, 7, 8, 9, 12, 31, 32, 33, 64, 100, 256})
+  // every (workgroup, iteration) pair maps to a distinct tile inside the grid and all tiles are covered, for the
+  // 256-row tiles of the one-workgroup-per-CU kernel and the 128-row tiles of the two-per-CU kernel
+  struct Form { int tile_h, group_m, wg_per_cu; };
+  for (const Form f : {Form{256, 4, 1}, Form{128, 8, 2}})
+  for (int tm : {1, 2, 3, 7, 8, 9, 12, 31, 32, 33, 64, 100, 256, 513})
     for (int tn : {1, 2, 3, 9, 12, 197})
       for (int cus : {0, 8, 64, 104, 250, 256, 304}) {
-        const int nwg = dpa::gemm_nt_grid(tm, tn, cus);
+        const int nwg = dpa::gemm_nt_grid(tm, tn, cus, f.wg_per_cu);
         CHECK(nwg >= 1 && (nwg % 8 == 0 || nwg == tm * tn));
-        dpa::GemmWalk w{tm, tn, nwg};
+        dpa::GemmWalk w{tm, tn, nwg, f.tile_h, f.group_m};
         std::vector<char> seen((size_t)tm * tn, 0);
         long long visited = 0;
         for (int wg = 0; wg < nwg; ++wg) {
@@ -103,8 +106,8 @@ static void test_gemm_walk() {
           CHECK(c >= 0);
           for (int it = 0; it < c; ++it) {
             const dpa::TileCoord t = w.at(wg, it);
-            CHECK(t.m0 % 256 == 0 && t.n0 % 256 == 0);
-            const int mi = t.m0 / 256, ni = t.n0 / 256;
+            CHECK(t.m0 % f.tile_h == 0 && t.n0 % 256 == 0);
+            const int mi = t.m0 / f.tile_h, ni = t.n0 / 256;
             CHECK(mi >= 0 && mi < tm && ni >= 0 && ni < tn);
             if (mi >= 0 && mi < tm && ni >= 0 && ni < tn) {
               CHECK(!seen[(size_t)mi * tn + ni]);
