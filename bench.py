@@ -62,7 +62,7 @@ def main():
                     help="dtype of the flat gradient buffers and of the gradient collectives")
     ap.add_argument("--rccl_max_channels", type=int, default=0, help="NCCL_MAX_NCHANNELS for RCCL (0: leave alone)")
     ap.add_argument("--rccl_min_channels", type=int, default=0, help="NCCL_MIN_NCHANNELS for RCCL (0: leave alone)")
-    ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high", "low"],
+    ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high"],
                     help="priority of the HIP stream the collectives run on (low: own communicator only)")
     ap.add_argument("--ep_capacity", type=float, default=0.0,
                     help="expert parallel: static per-peer capacity factor (0: exact variable all-to-all)")

@@ -84,13 +84,26 @@ struct RcclWork : torch::CustomClassHolder {
   hipEvent_t done = nullptr;
   int device = 0;
   std::vector<Tensor> held;   // operands of the collective, see the ordering contract above
+  hipStream_t issue_stream = nullptr;                       // the caller's stream when the collective was issued
+  c10::optional<c10::hip::HIPStream> comm_stream_;          // the stream the collective runs on
   explicit RcclWork(int dev) : device(dev) { DPA_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
   ~RcclWork() override {
+    // A handle that was never waited for (an exception unwound past it, a caller dropped it) must not hand its
+    // operands back to the allocator while the collective may still be reading or writing them.
+    if (done && !held.empty()) (void)hipEventSynchronize(done);
+    held.clear();
     if (done) (void)hipEventDestroy(done);
   }
   // device-side: the caller's current stream waits for the collective
   bool wait() {
-    DPA_HIP(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(device).stream(), done, 0));
+    const hipStream_t cur = c10::hip::getCurrentHIPStream(device).stream();
+    DPA_HIP(hipStreamWaitEvent(cur, done, 0));
+    // Ordering `cur` behind the collective protects reuse of the memory by `cur` only. The allocator hands a
+    // freed block back to the stream it was allocated on: if that is another stream than the one waiting here,
+    // tell the allocator that the communication stream used the block (it then defers the reuse by an event).
+    if (cur != issue_stream && comm_stream_.has_value())
+      for (const Tensor& t : held)
+        if (t.defined() && t.has_storage()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), *comm_stream_);
     held.clear();
     return true;
   }
@@ -111,9 +124,14 @@ struct RcclWork : torch::CustomClassHolder {
 // Communication streams live until the process ends and are shared by successive communicators of the
 // same (device, priority): the caching allocator may still have to record an event on one — for a
 // block that a collective used — long after the communicator that issued it is gone. High and default
-// priority streams come from PyTorch's stream pool (the allocator and the profiler know them; a lone
-// hand-made high-priority stream was seen to stall cross-stream event chains on this HIP stack); a
+// priority streams come from PyTorch's stream pool (the allocator and the profiler know them); a
 // stream below the default priority does not exist in that pool and is made here.
+// On ROCm 7.0.2 / RCCL 2.26.6 only the default priority is usable under this communicator: with one rank, RCCL
+// calls issued on a pool stream of high priority or on a hand-made low-priority stream stop completing after one
+// to five calls (benchmarks/debug/prio_diag.sh; the stall comes and goes between runs and is independent of
+// re-recording one 'ready' event, of the explicit group calls and of stream queries after the enqueue, while the
+// same event chain without RCCL calls, and c10d's high-priority option, run). The Python layer therefore refuses
+// both non-default priorities for this transport (parallel/comm.py); the parameter stays for stacks where it works.
 c10::hip::HIPStream comm_stream(int device, int priority) {
   static std::mutex mu;
   static std::vector<std::tuple<int, int, c10::hip::HIPStream>> pool;
@@ -141,6 +159,7 @@ struct Timed {
 struct RcclComm : torch::CustomClassHolder {
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
+  c10::optional<c10::hip::HIPStream> cstream;   // the same stream as a PyTorch object (allocator bookkeeping)
   hipEvent_t ready = nullptr;   // "inputs produced" marker, re-recorded per call (stream order makes that safe)
   int rank, world, device;
   int priority = 0;
@@ -175,19 +194,26 @@ struct RcclComm : torch::CustomClassHolder {
     priority = priority_ < 0 ? hi : (priority_ > 0 ? lo : 0);
     if (priority < hi) priority = hi;
     if (priority > lo) priority = lo;
-    stream = comm_stream(device, priority).stream();
+    cstream = comm_stream(device, priority);
+    stream = cstream->stream();
     DPA_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
     ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
     cfg.blocking = 1;
     if (min_ctas > 0) cfg.minCTAs = (int)min_ctas;
     if (max_ctas > 0) cfg.maxCTAs = (int)max_ctas;
     ncclResult_t r = ncclCommInitRankConfig(&comm, world, id, rank, &cfg);
-    if (r != ncclSuccess) {
-      // a library older than the header refuses the newer config record: fall back to the plain call
-      // (channel bounds then only come from NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS)
+    if (r == ncclInvalidArgument || r == ncclInvalidUsage) {
+      // A library older than the header refuses the newer config record before it talks to any peer: only then is
+      // the plain call on the same unique id safe (channel bounds then only come from NCCL_MIN_NCHANNELS /
+      // NCCL_MAX_NCHANNELS). Any other failure may have left a half-finished bootstrap behind on some ranks;
+      // retrying with the same id could hang the rendezvous and would hide the real error.
+      TORCH_WARN("RcclComm: ncclCommInitRankConfig refused its config (", ncclGetErrorString(r),
+                 "); creating the communicator without per-communicator channel bounds");
       comm = nullptr;
       min_ctas = max_ctas = 0;
       DPA_RCCL(ncclCommInitRank(&comm, world, id, rank));
+    } else {
+      TORCH_CHECK(r == ncclSuccess, "RCCL error in ncclCommInitRankConfig: ", ncclGetErrorString(r));
     }
   }
 
@@ -420,6 +446,8 @@ struct RcclComm : torch::CustomClassHolder {
     }
     auto work = c10::make_intrusive<RcclWork>(device);
     work->held.assign(used.begin(), used.end());
+    work->issue_stream = cur.stream();
+    work->comm_stream_ = cstream;
     DPA_HIP(hipEventRecord(work->done, stream));
     ++calls;
     return work;

@@ -66,15 +66,41 @@ def _all_ranks(flag: bool, device) -> bool:
     return t.item() > 0
 
 
+_NONE = -1          # encodings of "no such generation" / "no marker" in the broadcast triple
+_NO_MARKER = -2
+
+
+def _agreed_marker(path: str, rank: int, device):
+    """The commit marker as RANK 0 reads it, on every rank: (latest, previous | None), or None without one.
+    Only rank 0 writes the marker, and with node-local checkpoint directories only its node holds it, so a
+    rank that read its own copy could see another state (or none) and derive a different previous generation
+    or a different list of resume candidates, i.e. a different number of collectives. Collective."""
+    vals = [_NO_MARKER, _NONE]
+    if rank == 0:
+        m = _read_marker(path)
+        if m is not None:
+            vals = [m[0], m[1] if m[1] is not None else _NONE]
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    comm.broadcast(t, src=0)
+    latest, prev = (int(v) for v in t.tolist())
+    if latest == _NO_MARKER:
+        return None
+    return latest, (prev if prev != _NONE else None)
+
+
 def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None,
                 loader_states=None):
     """Resume point of iteration ``it`` as one file per rank (optimizer shards are rank-local), committed
-    as a set: every rank writes ``<path>.it<it>.rank<r>``, all ranks meet at a barrier, and only then
-    rank 0 atomically replaces the marker ``<path>.latest`` = {iter, prev, world}. A job that dies while
-    some ranks are still writing leaves the marker on the previous, complete generation, which is kept
-    until the new one is committed; older generations are deleted afterwards."""
+    as a set: rank 0 reads the current marker and every rank receives it (before anything changes), every rank
+    writes ``<path>.it<it>.rank<r>``, all ranks meet at a barrier, and only then rank 0 atomically replaces the
+    marker ``<path>.latest`` = {iter, prev, world}. A job that dies while some ranks are still writing leaves
+    the marker on the previous, complete generation, which is kept until the new one is committed; the
+    generation before that is deleted afterwards, by every rank from the SAME agreed marker (a rank that
+    re-read the file after the barrier could already see the new marker and would keep its old shard forever)."""
     import json
     Path(path).parent.mkdir(parents=True, exist_ok=True)
+    device = getattr(engine, "device", torch.device("cpu"))
+    old = _agreed_marker(path, rank, device)
     payload = {
         "iter": it,
         "world": world,
@@ -90,24 +116,25 @@ def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: in
     torch.save(payload, mine + ".tmp")
     os.replace(mine + ".tmp", mine)
     comm.barrier()                      # every rank's file of this generation is complete
-    old = _read_marker(path)
     prev = old[0] if old is not None and old[0] != it else (old[1] if old is not None else None)
     if rank == 0:
         with open(_marker(path) + ".tmp", "w") as f:
             json.dump({"iter": it, "prev": prev, "world": world}, f)
         os.replace(_marker(path) + ".tmp", _marker(path))
     comm.barrier()                      # the generation is committed
-    if old is not None and old[1] is not None and old[1] not in (it, prev):
-        try:
-            os.remove(_gen_file(path, old[1], rank))
-        except OSError:
-            pass
+    if old is not None:
+        for stale in {old[0], old[1]} - {it, prev, None}:
+            try:
+                os.remove(_gen_file(path, stale, rank))
+            except OSError:
+                pass
 
 
-def resume_candidates(path: str) -> list[int | None]:
+def resume_candidates(path: str, rank: int = 0, device=None) -> list[int | None]:
     """Iterations to try, newest first: the committed generation, then the one before it; a bare
-    ``<path>.rank<r>`` set (the single-generation layout of earlier versions) is tried last as None."""
-    m = _read_marker(path)
+    ``<path>.rank<r>`` set (the single-generation layout of earlier versions) is tried last as None. With a
+    ``device`` the list is rank 0's on every rank (collective); without, this process's own reading."""
+    m = _read_marker(path) if device is None else _agreed_marker(path, rank, device)
     out: list[int | None] = []
     if m is not None:
         out.append(m[0])
@@ -119,8 +146,9 @@ def resume_candidates(path: str) -> list[int | None]:
 
 def find_resume(path: str, rank: int, device) -> int | None | bool:
     """The newest generation whose file exists on EVERY rank: its iteration, None for the legacy
-    single-generation layout, or False when there is nothing to resume from. Collective."""
-    for it in resume_candidates(path):
+    single-generation layout, or False when there is nothing to resume from. Collective: every rank walks
+    rank 0's candidate list, so all of them issue the same sequence of all-reduces."""
+    for it in resume_candidates(path, rank, device):
         f = f"{path}.rank{rank}" if it is None else _gen_file(path, it, rank)
         if _all_ranks(os.path.exists(f), device):
             return it

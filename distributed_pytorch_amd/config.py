@@ -102,7 +102,7 @@ class Trainconfig:
     bucket_mb: float = 48.0           # gradient bucket size for DDP / ZeRO
     rccl_max_channels: int = 0        # NCCL_MAX_NCHANNELS of the RCCL communicator (0: RCCL's choice)
     rccl_min_channels: int = 0        # NCCL_MIN_NCHANNELS (0: RCCL's choice)
-    comm_priority: str = "default"    # priority of the stream the collectives run on: default | high | low (own)
+    comm_priority: str = "default"    # priority of the stream the collectives run on: default | high (c10d transport)
     vocab_parallel: bool = False      # split the head's vocabulary over the data-parallel ranks (ddp / zero / fsdp)
     ep_capacity: float = 0.0          # expert parallel: static capacity factor per peer (0 = exact, one host read / layer)
     tied_tail: str = "fused"          # tied lm_head/tkn_emb gradient: one all-reduce at the end | split (head part early)
@@ -235,7 +235,7 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--bucket_mb", type=float, default=tc.bucket_mb)
     p.add_argument("--rccl_max_channels", type=int, default=tc.rccl_max_channels)
     p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels)
-    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high", "low"])
+    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high"])
     p.add_argument("--vocab_parallel", action="store_true", default=tc.vocab_parallel)
     p.add_argument("--ep_capacity", type=float, default=tc.ep_capacity)
     p.add_argument("--tied_tail", type=str, default=tc.tied_tail, choices=["fused", "split"])

@@ -66,7 +66,11 @@ def rope_inplace_(x: torch.Tensor, cos_t, sin_t, pos0: int = 0, inverse: bool = 
 
 class _RopeQkvInplaceFn(torch.autograd.Function):
     """Rotate the leading ``heads`` heads of a fused projection ``[B, T, (heads + rest) * hs]`` IN PLACE
-    (the q and k heads of a qkv tensor the caller owns); the gradient is rotated back in place too."""
+    (the q and k heads of a qkv tensor the caller owns). The gradient is rotated back on a copy: autograd
+    does not promise that an incoming gradient belongs to this node alone (retain_graph and a second backward,
+    tensor hooks, a producer that keeps its buffer), and this path serves the attention fallbacks whose backward
+    arrives through split / cat nodes. The training path that does own its gradient buffer rotates inside the
+    attention backward kernels instead (``ops/attention.py::qkv_rope_attention``)."""
 
     @staticmethod
     def forward(ctx, qkv, cos_t, sin_t, pos0, heads, hs):
@@ -81,7 +85,7 @@ class _RopeQkvInplaceFn(torch.autograd.Function):
     def backward(ctx, dqkv):
         cos_t, sin_t = ctx.saved_tensors
         pos0, heads, hs = ctx.meta
-        d = dqkv if dqkv.is_contiguous() else dqkv.contiguous()
+        d = dqkv.clone(memory_format=torch.contiguous_format)
         B, T, _ = d.shape
         ops().rope_(d[..., : heads * hs].view(B, T, heads, hs), cos_t, sin_t, pos0, True)
         return d, None, None, None, None, None
@@ -90,9 +94,8 @@ class _RopeQkvInplaceFn(torch.autograd.Function):
 def rope_qkv_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, pos0: int, heads: int, hs: int) -> torch.Tensor:
     """Rotary embedding of the first ``heads`` heads of a fused ``[B, T, W]`` projection, without the copy
     of the rotated slice and the re-concatenation: one in-place pass over the q and k columns in
-    forward, one over their gradient in backward. ``qkv`` must be owned by the caller (a fresh GEMM
-    output that nothing else reads), and its only consumer must hand back a gradient tensor of its own
-    (the attention backward does: it allocates dqkv): that tensor is rotated in place as well."""
+    forward, one over a copy of their gradient in backward. ``qkv`` must be owned by the caller (a fresh GEMM
+    output that nothing else reads)."""
     ok = (use_hip(qkv, cos_t, sin_t) and qkv.dim() == 3 and qkv.is_contiguous() and hs % 8 == 0
           and qkv.dtype in (torch.bfloat16, torch.float32) and (qkv.shape[-1] * qkv.element_size()) % 16 == 0)
     if ok and (not qkv.requires_grad or not qkv.is_leaf):

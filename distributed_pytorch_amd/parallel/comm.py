@@ -60,28 +60,32 @@ _OWN = None          # torch.classes.dpa.RcclComm of the default group when the 
 _PRIORITIES = {"high": -1, "default": 0, "low": 1}
 
 
-def configure_rccl_env(max_channels: int = 0, min_channels: int = 0, stream_priority: str | None = None,
-                       backend: str | None = None):
+def configure_rccl_env(max_channels: int | None = None, min_channels: int | None = None,
+                       stream_priority: str | None = None, backend: str | None = None):
     """Environment of the RCCL communicator; call before ``init_distributed``.
 
     ``max_channels`` / ``min_channels`` (> 0) bound the number of RCCL channels, i.e. of workgroups
     (CUs) a collective's kernel occupies beside the backward pass: on the full xGMI mesh a handful of
     channels per peer saturates the links, and every channel beyond that only takes CUs away from the
     MFMA kernels. ``stream_priority`` ("default" | "high") is the priority of the HIP stream the
-    collectives run on (high: a ready collective's kernel is scheduled ahead of queued compute
-    kernels, so a bucket leaves as soon as it is complete; "low", own communicator only: collectives
-    only fill gaps the compute stream leaves). ``backend`` ("nccl" | "rccl" | "gloo") selects the
+    collectives run on (high, c10d transport only: a ready collective's kernel is scheduled ahead of queued
+    compute kernels, so a bucket leaves as soon as it is complete; see ``check_own_priority`` for why the own
+    communicator takes the default priority only). ``backend`` ("nccl" | "rccl" | "gloo") selects the
     transport, see the module docstring; with "rccl" the channel bounds are also given to that one
-    communicator as its CTA bounds instead of to every communicator of the process."""
+    communicator as its CTA bounds instead of to every communicator of the process. Arguments left at None
+    keep what an earlier call set (``init_distributed`` calls this once more with no arguments)."""
     # dmabuf IPC is the only mode the host driver supports on this pool.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # Keep the rendezvous on the loopback interface: container hostnames may not resolve.
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if max_channels > 0:
-        os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))
-    if min_channels > 0:
-        os.environ["NCCL_MIN_NCHANNELS"] = str(int(min_channels))
-    _SETTINGS["max_ctas"], _SETTINGS["min_ctas"] = max(int(max_channels), 0), max(int(min_channels), 0)
+    if max_channels is not None:
+        if max_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(int(max_channels))
+        _SETTINGS["max_ctas"] = max(int(max_channels), 0)
+    if min_channels is not None:
+        if min_channels > 0:
+            os.environ["NCCL_MIN_NCHANNELS"] = str(int(min_channels))
+        _SETTINGS["min_ctas"] = max(int(min_channels), 0)
     if stream_priority is not None:
         assert stream_priority in _PRIORITIES, stream_priority
         _SETTINGS["stream_priority"] = stream_priority
@@ -160,18 +164,27 @@ def _create_own(rank: int, world: int, device: torch.device):
     from .. import _ext
     assert _ext.available(), "the own RCCL communicator lives in the HIP extension (python build.py)"
     cls = torch.classes.dpa.RcclComm
-    if _SETTINGS["stream_priority"] == "high" and os.environ.get("DPA_OWN_HIGH_PRIORITY", "0") != "1":
-        # Measured on ROCm 7.0.2 / RCCL 2.26.6 (benchmarks/debug/prio_loop.py): RCCL calls issued directly on
-        # a high-priority stream stop completing after the fourth one, with every rank count and with or
-        # without channel bounds; the same event chain without RCCL, and c10d's high-priority option, run.
-        raise ValueError("--comm_priority high stalls under the own RCCL communicator on this ROCm stack; use "
-                         "--comm_backend c10d for a high-priority stream (DPA_OWN_HIGH_PRIORITY=1 overrides)")
+    check_own_priority(_SETTINGS["stream_priority"])
     uid = cls.unique_id() if rank == 0 else torch.zeros(128, dtype=torch.uint8)
     dist.broadcast(uid, src=0)
     _OWN = cls(uid, rank, world, device.index or 0, _PRIORITIES[_SETTINGS["stream_priority"]],
                _SETTINGS["min_ctas"], _SETTINGS["max_ctas"])
     seen = _OWN.comm_count()
     assert seen == world, f"RCCL reports {seen} ranks in the communicator, the launcher {world}"
+
+
+def check_own_priority(priority: str) -> None:
+    """The own communicator runs on a default-priority stream only. Measured on ROCm 7.0.2 / RCCL 2.26.6 with one
+    rank (benchmarks/debug/prio_diag.sh, profiles/r3_own_comm_priority_diagnosis.txt): RCCL calls issued on a
+    high-priority pool stream or on a hand-made low-priority stream stop completing after one to five calls, at a
+    call that changes from run to run; re-recording one event or a fresh one per call, explicit group calls or
+    none, and stream queries after the enqueue make no difference; the same event chain without RCCL calls and
+    c10d's high-priority option (``--comm_backend c10d --comm_priority high``) run. There is no override: a
+    priority that may hang a job at a random step is not an option to offer."""
+    if priority != "default":
+        raise ValueError(f"--comm_priority {priority} is not usable under the own RCCL communicator on this ROCm "
+                         "stack (collectives stop completing after a few calls); use the default priority, or "
+                         "--comm_backend c10d for a high-priority stream")
 
 
 def own_comm():

@@ -52,3 +52,25 @@ def test_preset_and_explicit_override():
 def test_mla_requires_latents():
     with pytest.raises(AssertionError):
         LLMconfig(attn="mla", q_latent_dim=None).finalize()
+
+
+def test_own_communicator_refuses_non_default_stream_priorities():
+    """A stream priority that stalls the own RCCL communicator after a few calls must not be selectable, and
+    there is no environment override; channel bounds set before init_distributed() survive its own call of
+    configure_rccl_env()."""
+    import pytest
+    from distributed_pytorch_amd.parallel import comm
+    comm.check_own_priority("default")
+    for p in ("high", "low"):
+        with pytest.raises(ValueError, match="not usable under the own RCCL communicator"):
+            comm.check_own_priority(p)
+    saved = dict(comm._SETTINGS)
+    try:
+        comm.configure_rccl_env(max_channels=8, min_channels=2)
+        comm.configure_rccl_env()            # what init_distributed() does
+        assert comm._SETTINGS["max_ctas"] == 8 and comm._SETTINGS["min_ctas"] == 2
+    finally:
+        comm._SETTINGS.update(saved)
+        import os
+        os.environ.pop("NCCL_MAX_NCHANNELS", None)
+        os.environ.pop("NCCL_MIN_NCHANNELS", None)

@@ -79,3 +79,54 @@ def _worker(rank, world, root, mode, scenario):
 @pytest.mark.parametrize("scenario", ["intact", "lost_file", "mixed"])
 def test_resume_generations_are_committed_as_a_set(tmp_path, scenario):
     assert all(run_distributed(_worker, 2, str(tmp_path), "zero2" if scenario != "mixed" else "ddp", scenario))
+
+
+def _worker_agreed(rank, world, root, layout):
+    """Only rank 0 ever reads the marker; every rank deletes from the value rank 0 saw BEFORE it was replaced,
+    whatever the timing between the ranks; with node-local directories (only rank 0's holds the marker) every
+    rank still walks the same candidate list."""
+    import time
+
+    import distributed_pytorch_amd.checkpoint as ck
+    path = os.path.join(root, f"node{rank}" if layout == "node_local" else "shared", "run_resume")
+    real_read = ck._read_marker
+
+    def guarded(p):
+        assert rank == 0, "a rank other than 0 read the commit marker"
+        return real_read(p)
+
+    real_barrier = ck.comm.barrier
+
+    def skewed_barrier(*a, **k):
+        # rank 0 runs ahead after every barrier (it replaces the marker at once), rank 1 lags behind it
+        real_barrier(*a, **k)
+        if rank == 1:
+            time.sleep(0.2)
+
+    ck._read_marker = guarded
+    ck.comm.barrier = skewed_barrier
+    try:
+        eng = _engine("zero2")
+        for it in range(4):
+            _step(eng, rank, it)
+            save_resume(path, eng, it, (), rank, world)
+            on_disk = sorted(int(f.split(".it")[1].split(".")[0]) for f in os.listdir(os.path.dirname(path))
+                             if f".rank{rank}" in f and ".it" in f)
+            assert on_disk == [i for i in (it - 1, it) if i >= 0], (rank, it, on_disk)
+        torch.distributed.barrier()
+        assert find_resume(path, rank, eng.device) == 3
+        if rank == 1:
+            os.remove(_gen_file(path, 3, rank))
+        torch.distributed.barrier()
+        assert find_resume(path, rank, eng.device) == 2
+        fresh = _engine("zero2")
+        assert load_resume(path, fresh, (), rank) == 2
+    finally:
+        ck._read_marker = real_read
+        ck.comm.barrier = real_barrier
+    return True
+
+
+@pytest.mark.parametrize("layout", ["shared", "node_local"])
+def test_marker_is_read_by_rank0_only_and_old_generations_go_on_every_rank(tmp_path, layout):
+    assert all(run_distributed(_worker_agreed, 2, str(tmp_path), layout))
