@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--bucket_mb", type=float, default=48.0)
+    ap.add_argument("--fsdp_prefetch", type=int, default=1, help="FSDP: units all-gathered ahead of the running block")
+    ap.add_argument("--fsdp_inflight", type=int, default=2, help="FSDP: reduce-scatters in flight before backward waits")
     ap.add_argument("--act_recomp", action="store_true")
     ap.add_argument("--act_recomp_scope", type=str, default="attn", choices=["attn", "block"])
     ap.add_argument("--hip_graph", action="store_true", help="replay the optimizer step from one hipGraph (1 GPU)")
@@ -63,7 +65,7 @@ def main():
     ap.add_argument("--rccl_max_channels", type=int, default=0, help="NCCL_MAX_NCHANNELS for RCCL (0: leave alone)")
     ap.add_argument("--rccl_min_channels", type=int, default=0, help="NCCL_MIN_NCHANNELS for RCCL (0: leave alone)")
     ap.add_argument("--comm_priority", type=str, default="default", choices=["default", "high"],
-                    help="priority of the HIP stream the collectives run on (low: own communicator only)")
+                    help="priority of the HIP stream the collectives run on (high: c10d transport only)")
     ap.add_argument("--ep_capacity", type=float, default=0.0,
                     help="expert parallel: static per-peer capacity factor (0: exact variable all-to-all)")
     ap.add_argument("--vocab_parallel", action="store_true", help="split the head's vocabulary over the ranks")
@@ -99,7 +101,8 @@ def main():
     tc = Trainconfig(dataset="synthetic", total_batch_size=global_batch * T, batch_size=B,
                      max_iters=args.steps + args.warmup, learning_rate=3e-4, warmup_steps=10, grad_clip=1.0,
                      bucket_mb=args.bucket_mb, dtype="bf16", grad_dtype=args.grad_dtype,
-                     ep_capacity=args.ep_capacity, vocab_parallel=args.vocab_parallel, tied_tail=args.tied_tail)
+                     ep_capacity=args.ep_capacity, vocab_parallel=args.vocab_parallel, tied_tail=args.tied_tail,
+                     fsdp_prefetch=args.fsdp_prefetch, fsdp_inflight=args.fsdp_inflight)
 
     data_dir = ensure_synthetic(os.path.join("/tmp", f"dpa_bench_data_v{mc.vocab_size}"), 1 << 24, mc.vocab_size, info.rank)
     check_vocab(os.path.join(data_dir, "train.bin"), mc.vocab_size)
@@ -147,20 +150,30 @@ def main():
         step = graph_step   # noqa: F811 - same contract, submitted as one graph
     for it in range(args.warmup):
         loss = step(it)
-    # what RCCL really spans: an all-reduce of ones over the job's process group
-    rccl_ranks = 1
+    # what RCCL really spans: an all-reduce of ones over the job's process group. Only a count that travelled
+    # through RCCL is reported as such: null for a single process and for the gloo rehearsal transport.
+    rccl_ranks = None
+    transport = "rccl(own)" if comm.own_comm() is not None else (info.backend if dist_job else "none")
     if dist_job:
         ones = torch.ones(1, dtype=torch.float32, device=info.device)
         comm.all_reduce(ones)
-        rccl_ranks = int(round(ones.item()))
+        spanned = int(round(ones.item()))
+        assert spanned == world, f"the process group spans {spanned} ranks, the launcher started {world}"
+        if transport in ("nccl", "rccl(own)"):
+            rccl_ranks = spanned
         if comm.own_comm() is not None:
-            assert comm.own_comm().comm_count() == rccl_ranks
+            assert comm.own_comm().comm_count() == spanned
     for k in comm.STATS:
         comm.STATS[k] = 0
     # Timed region: exactly args.steps steps between two (barrier + device synchronize) pairs; the whole
     # span is the throughput denominator. Each step is additionally bracketed by HIP events (no host
     # synchronisation inside the region) for the median / p10 / p90 step times.
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    from distributed_pytorch_amd.utils.profiling import exposed_comm
+    if dist_job:
+        exposed_comm.start()           # events around every wait of the compute stream for a collective
+        comm.set_comm_timing(True)     # own communicator: device time of every collective on its stream
+        comm.drain_comm_timings()
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -171,12 +184,17 @@ def main():
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = time.perf_counter() - t0
+    exposed_ms = exposed_comm.stop() / args.steps if dist_job else None
+    busy = {}
+    for kind, _, ms in (comm.drain_comm_timings() if dist_job else []):
+        busy[kind] = busy.get(kind, 0.0) + ms / args.steps
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     stats = torch.tensor([elapsed, step_ms[len(step_ms) // 2], step_ms[int(0.1 * (len(step_ms) - 1))],
-                          step_ms[int(round(0.9 * (len(step_ms) - 1)))]], dtype=torch.float64, device=info.device)
+                          step_ms[int(round(0.9 * (len(step_ms) - 1)))], exposed_ms or 0.0, sum(busy.values())],
+                         dtype=torch.float64, device=info.device)
     if dist_job:
         comm.all_reduce(stats, op=torch.distributed.ReduceOp.MAX)
-    elapsed, med_ms, p10_ms, p90_ms = stats.tolist()
+    elapsed, med_ms, p10_ms, p90_ms, exposed_max, busy_max = stats.tolist()
     final_loss = loss.item() * args.accum
     comm_bytes = {k: int(v) for k, v in comm.STATS.items() if v}
 
@@ -195,12 +213,21 @@ def main():
             "baseline_source": BASELINE_SOURCE if ref else None,
             "step_ms": {"median": med_ms, "mean": 1000 * elapsed / args.steps, "p10": p10_ms, "p90": p90_ms},
             "tokens_per_sec_median_step": tokens_step / (med_ms * 1e-3),
-            "rccl_ranks": rccl_ranks, "comm_bytes_per_step": {k: v // args.steps for k, v in comm_bytes.items()},
+            "rccl_ranks": rccl_ranks, "transport": transport,
+            "comm_bytes_per_step": {k: v // args.steps for k, v in comm_bytes.items()},
+            # per step, maximum over the ranks: time the compute stream waited for collectives (what backward and the
+            # optimizer did not hide), and device time of the collectives on the communication stream (own
+            # communicator only; null elsewhere): a scaling shortfall is exposed_comm_ms, the rest is compute
+            "exposed_comm_ms": exposed_max if dist_job else None,
+            "comm_busy_ms": (busy_max if comm.own_comm() is not None else None) if dist_job else None,
+            "comm_busy_ms_by_kind": ({k: round(v, 3) for k, v in busy.items()} if comm.own_comm() is not None else None),
+            "registered_buffers": getattr(engine, "registered_buffers", 0),
             "n_buckets": len(getattr(engine, "groups", [])), "grad_dtype": args.grad_dtype,
             "rccl_env": comm.rccl_settings(),
             "config": {"model": args.model, "params": total, "global_batch": global_batch, "micro_batch": B,
                        "seq_len": T, "grad_accum": args.accum,
-                       "parallelism": f"{mode}{world}" if world > 1 else "single", "optimizer": "fused AdamW",
+                       "parallelism": f"{mode}{world}" if world > 1 else "single", "engine": mode,
+                       "optimizer": "fused AdamW",
                        "grad_clip": tc.grad_clip, "hip_graph": bool(args.hip_graph)},
         }
         sys.stdout.flush()

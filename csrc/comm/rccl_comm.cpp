@@ -301,6 +301,11 @@ struct RcclComm : torch::CustomClassHolder {
     return true;
   }
 
+  int64_t num_registered() {
+    std::lock_guard<std::mutex> lk(mu);
+    return (int64_t)reg_handles.size();
+  }
+
   int64_t deregister_buffers() {
     std::lock_guard<std::mutex> lk(mu);
     if (stream) DPA_HIP(hipStreamSynchronize(stream));
@@ -474,6 +479,7 @@ TORCH_LIBRARY_FRAGMENT(dpa, m) {
       .def("set_timing", &RcclComm::set_timing)
       .def("drain_timings", &RcclComm::drain_timings)
       .def("register_buffer", &RcclComm::register_buffer)
+      .def("num_registered", &RcclComm::num_registered)
       .def("deregister_buffers", &RcclComm::deregister_buffers)
       .def("all_reduce", &RcclComm::all_reduce)
       .def("broadcast", &RcclComm::broadcast)

@@ -100,6 +100,8 @@ class Trainconfig:
     dtype: str = "auto"               # 'auto' -> bf16 on GPU, fp32 on CPU; or 'bf16' / 'fp32'
     grad_dtype: str = "auto"          # dtype of the flat gradient buffer / gradient collectives
     bucket_mb: float = 48.0           # gradient bucket size for DDP / ZeRO
+    fsdp_prefetch: int = 1            # FSDP: units all-gathered ahead of the running block (0: on demand)
+    fsdp_inflight: int = 2            # FSDP: reduce-scatters in flight before backward waits for the oldest
     rccl_max_channels: int = 0        # NCCL_MAX_NCHANNELS of the RCCL communicator (0: RCCL's choice)
     rccl_min_channels: int = 0        # NCCL_MIN_NCHANNELS (0: RCCL's choice)
     comm_priority: str = "default"    # priority of the stream the collectives run on: default | high (c10d transport)
@@ -233,6 +235,8 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--dtype", type=str, default=tc.dtype, choices=["auto", "bf16", "fp32"])
     p.add_argument("--grad_dtype", type=str, default=tc.grad_dtype, choices=["auto", "bf16", "fp32"])
     p.add_argument("--bucket_mb", type=float, default=tc.bucket_mb)
+    p.add_argument("--fsdp_prefetch", type=int, default=tc.fsdp_prefetch)
+    p.add_argument("--fsdp_inflight", type=int, default=tc.fsdp_inflight)
     p.add_argument("--rccl_max_channels", type=int, default=tc.rccl_max_channels)
     p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels)
     p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high"])

@@ -496,15 +496,30 @@ class MoE(nn.Module):
         B, T, C = x.shape
         x_flat = x.reshape(-1, C)
         topk_indices, topk_gates, aux_loss = self.route(x_flat)
-        # expert parallel: the dispatch exchange is issued first and travels while the shared experts run
-        pending = self.dispatcher.begin(self, x_flat, topk_indices, topk_gates) if self.dispatcher is not None else None
-        shared_output = None
-        for i in range(self.n_shared):
-            o = self.experts[i](x_flat)
-            shared_output = o if shared_output is None else shared_output + o
-        if pending is not None:
+        def shared(rows):
+            out = None
+            for i in range(self.n_shared):
+                o = self.experts[i](rows)
+                out = o if out is None else out + o
+            return out
+
+        if self.dispatcher is not None:
+            # Expert parallel: the dispatch exchange travels under the first half of the shared experts' rows, the
+            # return exchange under the second half (and in backward their reverses under the halves' backward).
+            N = x_flat.shape[0]
+            half = (N // 2 + 255) // 256 * 256 if N >= 1024 else N // 2   # whole GEMM row tiles where it matters
+            pending = self.dispatcher.begin(self, x_flat, topk_indices, topk_gates)
+            if self.n_shared > 0 and 0 < half < N and self.dispatcher.world > 1:   # (one rank: nothing travels)
+                s1 = shared(x_flat[:half])
+                pending = self.dispatcher.mid(pending)
+                s2 = shared(x_flat[half:])
+                shared_output = torch.cat([s1, s2], dim=0)
+            else:
+                shared_output = shared(x_flat)
+                pending = self.dispatcher.mid(pending)
             routed = self.dispatcher.finish(pending)
         else:
+            shared_output = shared(x_flat)
             routed = self.routed_experts_local(x_flat, topk_indices, topk_gates)
         y = routed if shared_output is None else shared_output + routed
         return y.view(B, T, C), aux_loss

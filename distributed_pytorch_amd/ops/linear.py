@@ -177,6 +177,45 @@ def _input_grad(dy2: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return torch.mm(dy2, w)
 
 
+# ---- deferred weight gradients --------------------------------------------------------------------------------
+# Expert-parallel layers want the input gradient of the local experts on the wire before the experts' weight
+# gradients are computed: the exchange of the input gradients then travels while those GEMMs run. Parameters marked
+# ``_dpa_defer`` (local experts of the expert-parallel engines: never reduced across ranks, accumulated straight
+# into the flat buffers, no bucket accounting waits for them) have their weight-gradient products queued while a
+# deferral window is open; ``flush_deferred_wgrads`` runs them (parallel/ep.py opens the window right before the
+# experts' backward and flushes it once the exchange of their input gradient has been issued; the engines flush
+# again before they read any gradient, so nothing is ever left behind).
+class _Deferral:
+    active = False
+    queue: list = []
+    log: list = []      # ("defer" | "run", n): what tests look at
+
+
+def begin_deferred_wgrads() -> None:
+    _Deferral.active = True
+
+
+def flush_deferred_wgrads() -> int:
+    """Run the queued weight-gradient products and close the window; returns how many ran."""
+    _Deferral.active = False
+    q, _Deferral.queue = _Deferral.queue, []
+    for fn in q:
+        fn()
+    if q:
+        _Deferral.log.append(("run", len(q)))
+    return len(q)
+
+
+def maybe_defer_wgrad(params, fn) -> bool:
+    """Queue ``fn`` (a closure that computes and accumulates the weight gradients of ``params`` into their flat
+    buffers) if a deferral window is open and every parameter allows it; False: the caller runs it now."""
+    if not _Deferral.active or not all(p is not None and getattr(p, "_dpa_defer", False) for p in params):
+        return False
+    _Deferral.queue.append(fn)
+    _Deferral.log.append(("defer", len(params)))
+    return True
+
+
 def _param_grads(w_param, b_param, dy2, x2, need_w: bool, need_b: bool):
     """(dw, db) of a Linear for autograd to accumulate, or (None, None) after folding them straight
     into the owning engine's flat gradient buffers (``w_param`` / ``b_param`` given and marked
@@ -187,6 +226,8 @@ def _param_grads(w_param, b_param, dy2, x2, need_w: bool, need_b: bool):
     target = _direct_target(w_param, dy2, x2) if (w_param is not None and need_w) else None
     if target is not None:
         btarget = _direct_bias_target(b_param) if need_b else None
+        if not need_b and maybe_defer_wgrad([w_param], lambda: ops().wgrad2_direct(dy2, x2, target, None)):
+            return None, None
         if need_b and btarget is None:
             slabs, dbf = ops().wgrad2_slabs_bias(dy2, x2)
             db = dbf.to(dy2.dtype)

@@ -232,6 +232,20 @@ def _grouped_wgrad(dy, x, seg_start, seg_rows):
     return ops().grouped_wgrad(dy, x, seg_start, seg_rows)
 
 
+def _wgrads(dy, x, seg_start, seg_rows, params, needs):
+    """Per-expert weight gradients of ``params`` from (dy, x): computed and emitted now, or, for parameters of an
+    expert-parallel engine while its deferral window is open (``ops/linear.py::maybe_defer_wgrad``), queued until
+    the exchange of the experts' input gradient is on the wire (they accumulate straight into the flat buffers,
+    so autograd gets None either way)."""
+    from .linear import maybe_defer_wgrad
+    targets = [_direct_grad(p) if needs[i] else None for i, p in enumerate(params)]
+    if all(needs) and all(t is not None for t in targets) and len({t.dtype for t in targets}) == 1:
+        if maybe_defer_wgrad(list(params),
+                             lambda: _emit_wgrads(_grouped_wgrad(dy, x, seg_start, seg_rows), params, needs)):
+            return [None] * len(params)
+    return _emit_wgrads(_grouped_wgrad(dy, x, seg_start, seg_rows), params, needs)
+
+
 def _emit_wgrads(ws32, params, needs):
     """fp32 [E, N, K] gradients -> per-parameter results: accumulated straight into the engine's
     flat gradient buffer when the parameters ask for it (``_dpa_direct``; one launch for all
@@ -288,14 +302,14 @@ class _GroupedExpertsFn(torch.autograd.Function):
         a = _act_fwd(h, ctx.act)
         g_proj = [None] * E
         if any(needs[E:]):
-            g_proj = _emit_wgrads(_grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
+            g_proj = _wgrads(dy, a, seg_start, seg_rows, proj, needs[E:])
         del a
         da = ops().grouped_gemm(dy, proj_ptrs, proj[0].shape[0], proj[0].shape[1], True, block_group)
         dh = _act_bwd(da, h, ctx.act)
         del da
         g_fc = [None] * E
         if any(needs[:E]):
-            g_fc = _emit_wgrads(_grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
+            g_fc = _wgrads(dh, xs, seg_start, seg_rows, fc, needs[:E])
         dx = None
         if ctx.needs_input_grad[0]:
             dxs = ops().grouped_gemm(dh, fc_ptrs, fc[0].shape[0], fc[0].shape[1], True, block_group)
@@ -364,7 +378,7 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
         dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
         g_proj = [None] * E
         if any(needs[E:]):
-            g_proj = _emit_wgrads(_grouped_wgrad(dy, a, seg_start, seg_rows), proj, needs[E:])
+            g_proj = _wgrads(dy, a, seg_start, seg_rows, proj, needs[E:])
         # dh = (dy W_proj) * gelu'(h), or the SwiGLU backward of it: NT on the per-step cached transposes, the
         # activation's derivative in the epilogue
         proj_t = [transposed_weight(w) for w in proj]          # [U, C] each
@@ -372,7 +386,7 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
                                    block_group)[0]
         g_fc = [None] * E
         if any(needs[:E]):
-            g_fc = _emit_wgrads(_grouped_wgrad(dh, xs, seg_start, seg_rows), fc, needs[:E])
+            g_fc = _wgrads(dh, xs, seg_start, seg_rows, fc, needs[:E])
         dx = None
         if ctx.needs_input_grad[0]:
             fc_t = [transposed_weight(w) for w in fc]          # [C, W] each

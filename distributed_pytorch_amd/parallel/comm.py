@@ -197,6 +197,17 @@ def register_buffer(t: torch.Tensor) -> bool:
     return bool(_OWN.register_buffer(t)) if _OWN is not None and t.is_cuda else False
 
 
+def registered_buffers() -> int:
+    """Number of buffers currently registered with the own communicator."""
+    return int(_OWN.num_registered()) if _OWN is not None else 0
+
+
+def deregister_buffers() -> int:
+    """Release every registration (after the communication stream has drained); returns how many there were.
+    ``shutdown()`` does the same before it destroys the communicator."""
+    return int(_OWN.deregister_buffers()) if _OWN is not None else 0
+
+
 def set_comm_timing(on: bool):
     """Device-side start/stop events around every collective of the own communicator."""
     if _OWN is not None:

@@ -76,6 +76,17 @@ class DDPEngine(Engine):
             for s in g.slots:
                 s.param.register_post_accumulate_grad_hook(self._make_hook(gi))
 
+    def _comm_buffers(self):
+        # the gradient buckets (all-reduced / reduce-scattered in place) and, for the sharded-optimizer engines,
+        # the parameter buffers their all-gather fills
+        reduced = self.groups[:getattr(self, "_n_dense_groups", len(self.groups))]   # (expert groups are never reduced)
+        bufs = [g.rgrad for g in reduced]
+        if getattr(self, "stage", 0) in (1, 2):
+            bufs += [g.data for g in reduced]
+        if self._head_sink is not None:
+            bufs.append(self._head_sink)
+        return bufs
+
     def _setup_split_tail(self):
         head = getattr(self.module, "lm_head", None)
         emb = getattr(self.module, "tkn_emb", None)
@@ -154,6 +165,7 @@ class DDPEngine(Engine):
         return comm.all_reduce(g.rgrad, group=self.group, async_op=True)
 
     def finish_grad_sync(self):
+        Engine.finish_grad_sync(self)
         if not self._dist:
             return
         if self.require_backward_grad_sync:

@@ -99,6 +99,7 @@ class Engine(nn.Module):
         self._dyn = None   # device {lr, bc1, bc2_sqrt} while a captured step is recorded / replayed (parallel/graph.py)
         self._sync_initial_state()
         self._build_storage()
+        self.registered_buffers = self._register_comm_buffers()
         self.optimizer = _OptimizerFacade(self, lr)
 
     # ---- construction ---------------------------------------------------------------------
@@ -129,6 +130,19 @@ class Engine(nn.Module):
         for g in self.groups:
             g.drop_init()
         self._enable_direct_grads()
+
+    def _comm_buffers(self):
+        """The persistent flat buffers this engine's collectives run on (same addresses for the whole run)."""
+        return []
+
+    def _register_comm_buffers(self) -> int:
+        """With the framework's own RCCL communicator, register the persistent flat buffers once, so that RCCL can
+        map them for direct peer access instead of staging every collective through its FIFO buffers. The library
+        may decline a buffer (the collective then runs as before); registrations are released by
+        ``comm.shutdown()`` / ``comm.deregister_buffers()``. Returns the number of accepted registrations."""
+        if not self._dist or comm.own_comm() is None or self.device.type != "cuda":
+            return 0
+        return sum(1 for t in self._comm_buffers() if t is not None and t.numel() > 0 and comm.register_buffer(t))
 
     def _enable_direct_grads(self):
         """Let the weight-gradient kernel accumulate straight into the flat gradient buffers
@@ -186,7 +200,10 @@ class Engine(nn.Module):
 
     # ---- gradient sync hooks for subclasses -----------------------------------------------
     def finish_grad_sync(self):
-        """Block the compute stream until every gradient collective has landed."""
+        """Block the compute stream until every gradient collective has landed (and run whatever weight-gradient
+        products an expert-parallel layer deferred and nobody flushed: none in a normal backward pass)."""
+        from ..ops.linear import flush_deferred_wgrads
+        flush_deferred_wgrads()
 
     def _grad_mul(self) -> float:
         return 1.0

@@ -14,8 +14,10 @@ Per MoE forward:
   4. each rank regroups what it received by local expert, runs its experts on contiguous
      slices, and sends the outputs back along the reverse all-to-all;
   5. scale by the gate and scatter-add into the token order.
-The all-to-all is an autograd function whose backward is the all-to-all with the split sizes
-swapped, so dispatch and combine are differentiable end to end.
+Every exchange is issued asynchronously and waited for right before its first consumer, in forward and
+in backward (the backward of an exchange is the exchange with the split sizes swapped): the two halves of
+the shared experts and the local experts' weight gradients run while the rows travel, see
+``ExpertParallelDispatcher``.
 
 Gradients: an expert receives every token routed to it from all ranks, so its gradient is
 already the global sum — expert parameters are NOT all-reduced; dense parameters are reduced
@@ -40,40 +42,69 @@ from .fsdp import FSDPEngine
 from .flat import FlatAdamW, FlatGroup, plan_groups, unique_named_parameters
 
 
-class _AllToAllRows(torch.autograd.Function):
-    """Row all-to-all(v). ``box`` (a list) receives the work handle when the forward exchange is issued
-    asynchronously: the caller waits on it before touching the result."""
+class _WaitGrad(torch.autograd.Function):
+    """Identity. In backward the incoming gradient may be the output of an exchange that ``_Exchange.backward``
+    issued and did not wait for: this node sits right in front of that gradient's first consumer and waits
+    there. Everything autograd runs between the two nodes (the backward of whatever the forward computed while
+    the forward exchange travelled: a half of the shared experts) runs under the exchange. ``open_defer``: the
+    node in front of the local experts also opens the deferral window for their weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, in_splits, out_splits, group, box):
-        ctx.splits = (in_splits, out_splits)
-        ctx.group = group
-        n_out = sum(out_splits) if out_splits is not None else x.shape[0]
-        out = x.new_empty((n_out,) + tuple(x.shape[1:]))
-        w = comm.all_to_all(out, x.contiguous(), out_splits, in_splits, group=group, async_op=box is not None)
-        if box is not None:
-            box.append(w)
-        return out
+    def forward(ctx, x, st, key, open_defer):
+        ctx.st, ctx.key, ctx.open_defer = st, key, open_defer
+        return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        in_splits, out_splits = ctx.splits
-        n_in = sum(in_splits) if in_splits is not None else g.shape[0]
-        gx = g.new_empty((n_in,) + tuple(g.shape[1:]))
-        comm.all_to_all(gx, g.contiguous(), in_splits, out_splits, group=ctx.group)
-        return gx, None, None, None, None
+        pending = ctx.st.pop(ctx.key, None)
+        if pending is not None:
+            ctx.st["log"].append(("wait", ctx.key))
+            pending[0].wait()
+        if ctx.open_defer:
+            from ..ops.linear import begin_deferred_wgrads
+            begin_deferred_wgrads()
+        return g, None, None, None
 
 
-def all_to_all_rows(x, in_splits, out_splits, group=None, box=None):
-    """Differentiable row exchange; ``None`` splits mean equal (static) splits."""
-    return _AllToAllRows.apply(x, None if in_splits is None else list(in_splits),
-                               None if out_splits is None else list(out_splits), group, box)
+class _Exchange(torch.autograd.Function):
+    """Autograd node of a row all-to-all(v) that was already issued on ``x`` (asynchronously, outside autograd)
+    and waited for: forward hands out the buffer it filled. Backward issues the reverse exchange of the incoming
+    gradient ASYNCHRONOUSLY and parks the work handle in ``st[key]`` for the ``_WaitGrad`` node in front of the
+    gradient's consumer; with ``flush`` the weight gradients the local experts deferred run right behind the
+    issue, i.e. while their input gradient is on the links."""
+
+    @staticmethod
+    def forward(ctx, x, out, in_splits, out_splits, group, st, key, flush):
+        ctx.meta = (tuple(x.shape), in_splits, out_splits, group, st, key, flush)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        xshape, in_splits, out_splits, group, st, key, flush = ctx.meta
+        gx = g.new_empty(xshape)
+        src = g.contiguous()
+        w = comm.all_to_all(gx, src, in_splits, out_splits, group=group, async_op=True)
+        st[key] = (w, src)                   # the source stays alive until the wait
+        st["log"].append(("issue", key))
+        if flush:
+            from ..ops.linear import flush_deferred_wgrads
+            n = flush_deferred_wgrads()
+            st["log"].append(("wgrads", n))
+        return gx, None, None, None, None, None, None, None
 
 
 class ExpertParallelDispatcher:
-    """Installed as ``MoE.dispatcher``. Two phases, so that the layer can run its shared experts while
-    the dispatch exchange is on the links: ``begin`` routes, sorts and issues the exchange
-    asynchronously; ``finish`` waits for it, runs the local experts and brings the results back.
+    """Installed as ``MoE.dispatcher``. Three phases, so that both exchanges of a layer travel under work that does
+    not depend on them:
+
+      ``begin``  routes, sorts and issues the dispatch exchange asynchronously        | first half of the shared experts
+      ``mid``    waits for it, runs the local experts, issues the return exchange     | second half of the shared experts
+      ``finish`` waits for it and combines.
+
+    Backward mirrors it through the autograd nodes above: the reverse of the return exchange is issued, the
+    second shared half's backward runs, the wait comes right before the local experts' backward; their weight
+    gradients are deferred, so the reverse of the dispatch exchange leaves as soon as their INPUT gradient exists
+    and travels under the weight-gradient GEMMs and the first shared half's backward.
 
     ``capacity`` = 0 (default): exact. The per-peer row counts are read back to the host once per layer
     (they are the split sizes of a variable all-to-all) and every routed pair is served.
@@ -89,6 +120,7 @@ class ExpertParallelDispatcher:
         self.rank = comm.get_rank(group)
         self.capacity = float(capacity)
         self.dropped = None        # device counter of pairs dropped by the capacity bound
+        self.last_log = None       # event log of the most recent layer (forward and backward), for tests / debugging
 
     def local_expert_range(self, n_routed: int):
         assert n_routed % self.world == 0, "n_routed must be divisible by the expert-parallel world size"
@@ -99,7 +131,14 @@ class ExpertParallelDispatcher:
         return int(self.dropped.item()) if self.dropped is not None else 0
 
     def __call__(self, moe, x_flat, topk_indices, topk_gates):
-        return self.finish(self.begin(moe, x_flat, topk_indices, topk_gates))
+        return self.finish(self.mid(self.begin(moe, x_flat, topk_indices, topk_gates)))
+
+    def _issue(self, st, src, n_out, in_splits, out_splits, key):
+        """Asynchronous exchange of ``src`` (outside autograd) -> (buffer, work handle)."""
+        buf = src.new_empty((n_out,) + tuple(src.shape[1:]))
+        w = comm.all_to_all(buf, src.detach().contiguous(), out_splits, in_splits, group=self.group, async_op=True)
+        st["log"].append(("issue", key))
+        return buf, w
 
     # ---- phase 1 --------------------------------------------------------------------------------
     def begin(self, moe, x_flat, topk_indices, topk_gates):
@@ -108,7 +147,8 @@ class ExpertParallelDispatcher:
         # expert-sorted (== destination-rank-sorted) send order, computed on the device
         row_of_pair, counts = ops.plan_dense(topk_indices, moe.n_routed)   # counts: rows per expert (global ids)
         xs = ops.scatter_rows(x_flat, row_of_pair, k, N * k)
-        st = dict(moe=moe, x_flat=x_flat, row_of_pair=row_of_pair, gates=topk_gates, k=k, per=per, box=[])
+        st = dict(moe=moe, x_flat=x_flat, row_of_pair=row_of_pair, gates=topk_gates, k=k, per=per, log=[])
+        self.last_log = st["log"]
         if self.capacity > 0:
             cap = -(-int(self.capacity * N * k) // W)
             cap = max(8, (cap + 7) // 8 * 8)
@@ -126,16 +166,21 @@ class ExpertParallelDispatcher:
             send = xs.index_select(0, src) * valid[:, None].to(xs.dtype)
             recv_cnt = torch.empty_like(send_cnt)
             comm.all_to_all(recv_cnt, send_cnt.contiguous(), group=self.group)   # [src rank][local expert]
-            recv = all_to_all_rows(send, None, None, self.group, st["box"])
-            st.update(cap=cap, src=src, valid=valid, recv_cnt=recv_cnt, recv=recv, npairs=N * k)
-            return st
-        recv_counts = torch.empty_like(counts)
-        comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
-        recv_mat = recv_counts.view(W, per)
-        # the one host read of the layer: rows sent to / received from each rank (the all-to-all splits)
-        counts_h, recv_h = torch.stack([counts.view(W, per).sum(1), recv_mat.sum(1)]).tolist()
-        recv = all_to_all_rows(xs, counts_h, recv_h, self.group, st["box"])
-        st.update(recv=recv, recv_mat=recv_mat, counts_h=counts_h, recv_h=recv_h)
+            st.update(cap=cap, src=src, valid=valid, recv_cnt=recv_cnt, npairs=N * k, in_splits=None, out_splits=None)
+            n_out = W * cap
+        else:
+            recv_counts = torch.empty_like(counts)
+            comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
+            recv_mat = recv_counts.view(W, per)
+            # the one host read of the layer: rows sent to / received from each rank (the all-to-all splits)
+            counts_h, recv_h = torch.stack([counts.view(W, per).sum(1), recv_mat.sum(1)]).tolist()
+            counts_h, recv_h = [int(v) for v in counts_h], [int(v) for v in recv_h]
+            send = xs
+            st.update(recv_mat=recv_mat, in_splits=counts_h, out_splits=recv_h)
+            n_out = sum(recv_h)
+        send_w = _WaitGrad.apply(send, st, "dispatch_bwd", False)
+        st["send_w"] = send_w
+        st["recv_buf"], st["work"] = self._issue(st, send_w, n_out, st["in_splits"], st["out_splits"], "dispatch")
         return st
 
     # ---- phase 2 --------------------------------------------------------------------------------
@@ -157,11 +202,12 @@ class ExpertParallelDispatcher:
                                        projs, act)
         return None
 
-    def finish(self, st):
+    def mid(self, st):
         moe, per, W = st["moe"], st["per"], self.world
-        for w in st["box"]:
-            w.wait()
-        recv = st["recv"]
+        st.pop("work").wait()
+        st["log"].append(("wait", "dispatch"))
+        recv = _Exchange.apply(st["send_w"], st.pop("recv_buf"), st["in_splits"], st["out_splits"], self.group, st,
+                               "dispatch_bwd", True)
         R = recv.shape[0]
         if self.capacity > 0:
             cap = st["cap"]
@@ -176,34 +222,52 @@ class ExpertParallelDispatcher:
                 for e in range(per):
                     m = ((row_expert == e) & row_valid)[:, None].to(recv.dtype)
                     y_recv = y_recv + moe.experts[moe.n_shared + lo + e].expert(recv) * m
-            y_back = all_to_all_rows(y_recv, None, None, self.group)
-            y_sorted = torch.zeros(st["npairs"], recv.shape[1], dtype=y_back.dtype, device=y_back.device)
+            n_back = W * cap
+        else:
+            recv_mat = st["recv_mat"]
+            # regroup the received rows (ordered by source rank, then expert) by local expert
+            seg_expert = torch.arange(per, device=recv.device).repeat(W)        # expert id of each (src, expert) segment
+            row_expert = torch.repeat_interleave(seg_expert, recv_mat.reshape(-1), output_size=R)
+            y_recv = self._local_experts(moe, recv, row_expert, torch.ones(R, device=recv.device), per)
+            if y_recv is None:
+                lo = self.rank * per
+                local = [moe.experts[moe.n_shared + lo + j].expert for j in range(per)]
+                perm = torch.argsort(row_expert, stable=True)
+                per_expert = recv_mat.sum(0).tolist()
+                grouped = recv[perm]
+                outs, start = [], 0
+                for j, c in enumerate(per_expert):
+                    c = int(c)
+                    if c:
+                        outs.append(local[j](grouped[start:start + c]))
+                    start += c
+                if outs:
+                    y_grouped = torch.cat(outs, dim=0)
+                else:
+                    y_grouped = grouped.new_zeros((0, st["x_flat"].shape[1]))
+                    # keep the local experts in the autograd graph so their (zero) gradients exist
+                    y_grouped = y_grouped + 0.0 * sum(p.sum() for m in local for p in m.parameters())
+                y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
+            n_back = sum(st["in_splits"])
+        # the node in front of the local experts' backward: waits for the reverse of the return exchange and opens
+        # the deferral window for the experts' weight gradients
+        y_w = _WaitGrad.apply(y_recv, st, "return_bwd", True)
+        st["y_w"] = y_w
+        st["back_buf"], st["work"] = self._issue(st, y_w, n_back, st["out_splits"], st["in_splits"], "return")
+        return st
+
+    # ---- phase 3 --------------------------------------------------------------------------------
+    def finish(self, st):
+        if "y_w" not in st:
+            st = self.mid(st)
+        st.pop("work").wait()
+        st["log"].append(("wait", "return"))
+        y_back = _Exchange.apply(st.pop("y_w"), st.pop("back_buf"), st["out_splits"], st["in_splits"], self.group, st,
+                                 "return_bwd", False)
+        if self.capacity > 0:
+            y_sorted = torch.zeros(st["npairs"], y_back.shape[1], dtype=y_back.dtype, device=y_back.device)
             y_sorted = y_sorted.index_add(0, st["src"], y_back * st["valid"][:, None].to(y_back.dtype))
             return ops.gather_combine(y_sorted, st["row_of_pair"], st["gates"], st["k"]).to(st["x_flat"].dtype)
-        recv_mat = st["recv_mat"]
-        # regroup the received rows (ordered by source rank, then expert) by local expert
-        seg_expert = torch.arange(per, device=recv.device).repeat(W)        # expert id of each (src, expert) segment
-        row_expert = torch.repeat_interleave(seg_expert, recv_mat.reshape(-1), output_size=R)
-        y_recv = self._local_experts(moe, recv, row_expert, torch.ones(R, device=recv.device), per)
-        if y_recv is None:
-            lo = self.rank * per
-            local = [moe.experts[moe.n_shared + lo + j].expert for j in range(per)]
-            perm = torch.argsort(row_expert, stable=True)
-            per_expert = recv_mat.sum(0).tolist()
-            grouped = recv[perm]
-            outs, start = [], 0
-            for j, c in enumerate(per_expert):
-                if c:
-                    outs.append(local[j](grouped[start:start + c]))
-                start += c
-            if outs:
-                y_grouped = torch.cat(outs, dim=0)
-            else:
-                y_grouped = grouped.new_zeros((0, st["x_flat"].shape[1]))
-                # keep the local experts in the autograd graph so their (zero) gradients exist
-                y_grouped = y_grouped + 0.0 * sum(p.sum() for m in local for p in m.parameters())
-            y_recv = torch.empty_like(y_grouped).index_copy_(0, perm, y_grouped) if R else y_grouped
-        y_back = all_to_all_rows(y_recv, st["recv_h"], st["counts_h"], self.group)
         return ops.gather_combine(y_back, st["row_of_pair"], st["gates"], st["k"]).to(st["x_flat"].dtype)
 
 
@@ -332,6 +396,9 @@ def _drop_remote_experts(engine, cfg):
         if ei is not None and ei >= cfg.n_shared:
             if lo <= ei - cfg.n_shared < hi:
                 local_named.append((n, p))
+                # never reduced across ranks and no bucket accounting waits for it: its weight-gradient product
+                # may run after the exchange of the experts' input gradient has been issued (ops/linear.py)
+                p._dpa_defer = True
             else:
                 p.requires_grad_(False)
                 p.data = torch.empty(0, dtype=p.dtype, device=p.device)   # not owned here: free it

@@ -95,7 +95,9 @@ class FSDPUnit(FlatGroup):
             return
         if self.gather_work is None:
             self.begin_gather(group)
-        self.gather_work.wait()
+        from ..utils.profiling import comm_wait_range
+        with comm_wait_range():       # a gather the prefetch did not hide
+            self.gather_work.wait()
         self.gather_work = None
         self.gathered = True
 
@@ -140,8 +142,16 @@ class FSDPUnit(FlatGroup):
 class FSDPEngine(Engine):
     name = "fsdp"
 
-    def __init__(self, model, reshard_after_forward: bool = True, **kw):
+    def __init__(self, model, reshard_after_forward: bool = True, prefetch: int = 1, inflight: int = 2, **kw):
+        """``prefetch``: units whose all-gather is issued ahead of the block that is about to run (forward: the
+        next ``prefetch`` blocks, backward: the previous ones); 0 gathers on demand. Each unit in flight is one
+        more full parameter buffer alive (100 MB per block of GPT-2-1.3B against 288 GB of HBM), and on a full
+        xGMI mesh an all-gather is bound by the per-link rate, so a second gather in flight fills links the
+        first one leaves idle only if RCCL runs them on separate channels. ``inflight``: reduce-scatters (full
+        gradient buffers) allowed in flight before backward waits for the oldest."""
         self.reshard_after_forward = reshard_after_forward
+        self.prefetch = max(int(prefetch), 0)
+        self.inflight = max(int(inflight), 1)
         super().__init__(model, **kw)
 
     # ---- construction ---------------------------------------------------------------------
@@ -175,12 +185,19 @@ class FSDPEngine(Engine):
         for u in self.block_units:
             u.release_params()
 
+    def _comm_buffers(self):
+        # the persistent shards: inputs of the all-gathers, outputs of the reduce-scatters (the full buffers come
+        # and go with the storage resizes and are not registered)
+        return [t for u in self.units for t in (u.shard, u.grad_shard)]
+
     # ---- hooks ----------------------------------------------------------------------------
     def _make_pre_fwd(self, i):
         def hook(module, args):
             n = len(self.block_units)
-            if i + 1 < n and not _in_recompute():   # (a recomputed block is followed by block i-1, not i+1)
-                self.block_units[i + 1].begin_gather(self.group)   # prefetch the next unit first
+            if not _in_recompute():   # (a recomputed block is followed by block i-1, not i+1)
+                for d in range(1, self.prefetch + 1):   # prefetch the next units first
+                    if i + d < n:
+                        self.block_units[i + d].begin_gather(self.group)
             self.block_units[i].wait_gather(self.group)
         return hook
 
@@ -196,8 +213,9 @@ class FSDPEngine(Engine):
 
     def _make_pre_bwd(self, i):
         def hook(module, grad_output):
-            if i - 1 >= 0:
-                self.block_units[i - 1].begin_gather(self.group)
+            for d in range(1, self.prefetch + 1):
+                if i - d >= 0:
+                    self.block_units[i - d].begin_gather(self.group)
             u = self.block_units[i]
             u.wait_gather(self.group)
             u.materialize_grad()
@@ -225,7 +243,7 @@ class FSDPEngine(Engine):
         if u is not self.root and self.reshard_after_forward:
             u.release_params()
         self._rs_inflight.append((w, u))
-        while len(self._rs_inflight) > 2:   # bound the number of full gradient buffers alive
+        while len(self._rs_inflight) > self.inflight:   # bound the number of full gradient buffers alive
             w0, u0 = self._rs_inflight.popleft()
             w0.wait()
             u0.rs_work = None
@@ -256,6 +274,7 @@ class FSDPEngine(Engine):
         self._have_norm = False
 
     def finish_grad_sync(self):
+        Engine.finish_grad_sync(self)
         if self.require_backward_grad_sync:
             for u in reversed(self.units):          # units whose hooks did not all fire
                 if u.grad_alive and not getattr(u, "reduced", False):

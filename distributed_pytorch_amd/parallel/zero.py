@@ -70,8 +70,10 @@ class ZeroEngine(DDPEngine):
             self._gather_works.append(comm.all_gather(g.data, g.data[o.lo:o.hi], group=self.group, async_op=True))
 
     def _post_step(self):
-        for w in self._gather_works:
-            w.wait()
+        from ..utils.profiling import comm_wait_range
+        with comm_wait_range():       # parameter all-gathers the remaining AdamW launches did not hide
+            for w in self._gather_works:
+                w.wait()
         self._gather_works = []
         super()._post_step()
 

@@ -77,13 +77,14 @@ def build_engine(mode: str, model: LLM, tc: Trainconfig, info: comm.DistInfo):
         return ZeroEngine(model, stage=int(mode[-1]), **kw)
     if mode in ("fsdp", "fsdp_keep"):
         from .parallel.fsdp import FSDPEngine
-        return FSDPEngine(model, reshard_after_forward=(mode == "fsdp"), **kw)
+        return FSDPEngine(model, reshard_after_forward=(mode == "fsdp"), prefetch=getattr(tc, "fsdp_prefetch", 1),
+                          inflight=getattr(tc, "fsdp_inflight", 2), **kw)
     if mode == "ep":
         from .parallel.ep import EPEngine
         return EPEngine(model, **kw)
     if mode == "ep_fsdp":
         from .parallel.ep import EPFSDPEngine
-        return EPFSDPEngine(model, **kw)
+        return EPFSDPEngine(model, prefetch=getattr(tc, "fsdp_prefetch", 1), inflight=getattr(tc, "fsdp_inflight", 2), **kw)
     raise ValueError(f"unknown parallel mode {mode!r}")
 
 

@@ -160,11 +160,51 @@ def comm_range(kind: str, nbytes: int = 0):
     return _active.phase(f"comm_issue:{kind}", nbytes=nbytes, host_only=True)
 
 
+class ExposedComm:
+    """Exposed communication without a profiling run: while ``start()`` is in effect, every wait of the compute
+    stream for outstanding collectives (the ``comm_wait_range`` sections of the engines) is bracketed by two HIP
+    events on that stream; ``stop()`` reads them once and returns the total milliseconds the stream spent there.
+    No host synchronisation happens inside the measured region (bench.py reports it per step)."""
+
+    def __init__(self):
+        self.on = False
+        self.pairs = []
+
+    def start(self):
+        self.pairs = []
+        self.on = torch.cuda.is_available()
+
+    @contextlib.contextmanager
+    def section(self):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        try:
+            yield
+        finally:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.append((e0, e1))
+
+    def stop(self) -> float:
+        self.on = False
+        if not self.pairs:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self.pairs)
+        self.pairs = []
+        return ms
+
+
+exposed_comm = ExposedComm()
+
+
 def comm_wait_range():
     """Context of the compute stream waiting for outstanding collectives (exposed communication)."""
-    if _active is None or not _active.enabled:
-        return contextlib.nullcontext()
-    return _active.phase("comm_wait")
+    if _active is not None and _active.enabled:
+        return _active.phase("comm_wait")
+    if exposed_comm.on:
+        return exposed_comm.section()
+    return contextlib.nullcontext()
 
 
 class KernelTable:

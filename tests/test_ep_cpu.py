@@ -181,3 +181,37 @@ def test_ep_one_expert_per_rank(capacity):
     got = outs[0][2]
     for k in sd:
         assert torch.allclose(got[k].float(), sd[k].float(), rtol=2e-4, atol=2e-5), f"{k} differs after the step"
+
+
+def _worker_overlap(rank, world):
+    """Order of the exchanges, waits and independent work of one MoE layer, forward and backward."""
+    from distributed_pytorch_amd.parallel.ep import EPEngine
+    model, cfg = _make(False)
+    eng = EPEngine(model, weight_decay=0.0, dtype="fp32", eps=1e-5, bucket_mb=0.01)
+    disp = eng.dispatcher
+    last = eng.module.transformer.h[-1].moe
+    last.experts[0].register_full_backward_hook(lambda m, gi, go: disp.last_log.append(("shared_bwd", None)))
+    last.experts[0].register_forward_hook(lambda m, a, o: disp.last_log.append(("shared_fwd", None)))
+    xb = _batch(cfg, 4)
+    x = xb[rank * 2:(rank + 1) * 2]
+    eng.zero_grad()
+    _, loss, _ = eng(x, x.roll(-1, 1))
+    log = disp.last_log           # the last layer's: its backward events are appended to the same list
+    n_fwd = len(log)
+    loss.backward()
+    eng.finish_grad_sync()
+    return [e for e in log[:n_fwd]], [e for e in log[n_fwd:]]
+
+
+def test_ep_exchanges_travel_under_independent_work():
+    """Forward: each exchange is issued, a half of the shared experts runs, only then is it waited for. Backward:
+    the reverse of the return exchange is issued before the second shared half's backward and waited for after
+    it; the reverse of the dispatch exchange is issued, the deferred weight gradients of the local experts run
+    (a work handle exists before they do), the first shared half's backward runs, and the wait comes last."""
+    for fwd, bwd in run_distributed(_worker_overlap, 2):
+        assert fwd == [("issue", "dispatch"), ("shared_fwd", None), ("wait", "dispatch"), ("issue", "return"),
+                       ("shared_fwd", None), ("wait", "return")], fwd
+        kinds = [e for e in bwd if e[0] != "wgrads"]
+        assert kinds == [("issue", "return_bwd"), ("shared_bwd", None), ("wait", "return_bwd"),
+                         ("issue", "dispatch_bwd"), ("shared_bwd", None), ("wait", "dispatch_bwd")], bwd
+        assert bwd.index(("issue", "dispatch_bwd")) + 1 == [i for i, e in enumerate(bwd) if e[0] == "wgrads"][0]

@@ -149,10 +149,23 @@ def test_engines_over_the_own_communicator_match_single(own_as_default_group, ow
     torch.manual_seed(1)
     ref = _run(build_engine("single", LLM(cfg), tc, own_as_default_group), cfg)
     calls, before = own.num_calls(), dict(comm.STATS)
+    import importlib
+    lin = importlib.import_module("distributed_pytorch_amd.ops.linear")   # (ops.linear the attribute is the function)
+    lin._Deferral.log.clear()
     torch.manual_seed(1)
+    assert own.num_registered() == 0
     eng = build_engine(mode, LLM(cfg), tc, own_as_default_group)
     assert eng._dist
+    # the persistent flat buffers of the engine were offered to RCCL for registration (it may decline them all)
+    assert eng.registered_buffers == own.num_registered() <= len(eng._comm_buffers())
+    assert len(eng._comm_buffers()) >= (2 if mode != "ddp" else 1)
     got = _run(eng, cfg)
+    if mode == "ep":
+        # the local experts' weight gradients were deferred behind the exchange of their input gradient and ran
+        kinds = [k for k, _ in lin._Deferral.log]
+        assert "defer" in kinds and "run" in kinds and not lin._Deferral.queue
+    # registrations are released while the buffers are still allocated
+    assert comm.deregister_buffers() == eng.registered_buffers and own.num_registered() == 0
     assert own.num_calls() > calls + 6, "the collectives did not go through the own communicator"
     moved = {k: comm.STATS[k] - before[k] for k in before}
     if mode in ("zero2", "fsdp"):
