@@ -109,6 +109,7 @@ def main():
     loader = DataLoader(B, T, os.path.join(data_dir, "train.bin"), info.device, info.rank, world, 1729)
 
     model = LLM(mc)
+    model.loss_grad_scale = 1.0 / args.accum
     total, active = model.get_num_params()
     flops_tok = model_flops_per_token(model, T)
     engine = build_engine(mode, model, tc, info)

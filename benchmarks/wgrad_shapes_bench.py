@@ -24,7 +24,10 @@ CASES = {
     "124m": (65536, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
     "350m": (32768, [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]),
     "1.3b": (16384, [(6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192)]),
+    "1.3b, micro-batch 48": (49152, [(6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192)]),
 }
+if os.environ.get("WGRAD_CASES"):
+    CASES = {k: v for k, v in CASES.items() if k in os.environ["WGRAD_CASES"].split(";")}
 for name, (M, shapes) in CASES.items():
     for (N, K) in shapes:
         dy = torch.randn(M, N, device="cuda").to(torch.bfloat16)

@@ -846,6 +846,14 @@ std::tuple<Tensor, Tensor> wgrad2_slabs_bias(const Tensor& dy, const Tensor& x) 
   return {slabs, colsum(dy)};
 }
 
+void scale_unless(Tensor x, const Tensor& g, double expected) {
+  check_act(x, "x");
+  TORCH_CHECK(x.is_contiguous() && x.numel() % 8 == 0, "scale_unless: contiguous tensor of a multiple of 8 elements");
+  TORCH_CHECK(g.is_cuda() && g.scalar_type() == at::kFloat && g.numel() == 1, "scale_unless: g is one fp32 value on the device");
+  TORCH_CHECK(expected != 0.0, "scale_unless: expected factor must not be zero");
+  dpa::scale_unless(x.data_ptr(), x.numel(), is_bf16(x), g.data_ptr<float>(), (float)expected, cur_stream());
+}
+
 // dw_acc [N, K] += dy^T x and, when given, db_acc [N] += column sums of dy: the weight-gradient GEMM
 // and the folds of its per-split slabs, with both results accumulated in place (bf16 or fp32
 // destinations, typically views of a flat gradient buffer).
@@ -861,22 +869,27 @@ void wgrad2_direct(const Tensor& dy, const Tensor& x, Tensor dw_acc, const std::
     TORCH_CHECK(db_acc->numel() == N && N % 8 == 0, "wgrad2_direct: db_acc must hold N elements (N % 8 == 0)");
   }
   const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
-  Tensor slabs = at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
+  // one split of the 256 x 256 kernel: it adds into the gradient itself (no slab, no fold)
+  const bool direct = dpa::wgrad2_direct_ok((int)M, (int)N, (int)K) && dw_acc.is_contiguous();
+  Tensor slabs = direct ? Tensor() : at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
+  float* slab_ptr = direct ? nullptr : slabs.data_ptr<float>();
+  void* dptr = direct ? dw_acc.data_ptr() : nullptr;
   if (db_acc.has_value() && dpa::wgrad2_fuses_bias((int)M, (int)N, (int)K)) {
     const int bs = dpa::wgrad2_bias_slabs((int)M, (int)N, (int)K);
     Tensor bslabs = at::empty({bs, N}, dy.options().dtype(at::kFloat));
-    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
-                     x.stride(0), splits, cur_stream(), bslabs.data_ptr<float>());
+    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slab_ptr, (int)M, (int)N, (int)K, dy.stride(0),
+                     x.stride(0), splits, cur_stream(), bslabs.data_ptr<float>(), dptr, is_bf16(dw_acc));
     dpa::wgrad_finish(bslabs.data_ptr<float>(), db_acc->data_ptr(), N, bs, true, is_bf16(*db_acc), cur_stream());
   } else {
-    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slabs.data_ptr<float>(), (int)M, (int)N, (int)K, dy.stride(0),
-                     x.stride(0), splits, cur_stream());
+    dpa::wgrad2_gemm(dy.data_ptr(), x.data_ptr(), slab_ptr, (int)M, (int)N, (int)K, dy.stride(0),
+                     x.stride(0), splits, cur_stream(), nullptr, dptr, is_bf16(dw_acc));
     if (db_acc.has_value()) {
       Tensor cs = colsum(dy);
       dpa::wgrad_finish(cs.data_ptr<float>(), db_acc->data_ptr(), N, 1, true, is_bf16(*db_acc), cur_stream());
     }
   }
-  dpa::wgrad_finish(slabs.data_ptr<float>(), dw_acc.data_ptr(), N * K, splits, true, is_bf16(dw_acc), cur_stream());
+  if (!direct)
+    dpa::wgrad_finish(slabs.data_ptr<float>(), dw_acc.data_ptr(), N * K, splits, true, is_bf16(dw_acc), cur_stream());
 }
 
 // dst_g (+)= ws[g] for every g: ws fp32 [G, ...], dst_ptrs int64 [G] device addresses of equally sized,
@@ -1241,6 +1254,8 @@ TORCH_LIBRARY(dpa, m) {
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
   m.def("wgrad2(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_set_stages(int s) -> ()");
+  m.def("scale_unless(Tensor(a!) x, Tensor g, float expected) -> ()");
+  m.def("wgrad2_force_splits(int s) -> ()");
   m.def("clear_last_error() -> int");
   m.def("wgrad2_slabs(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_accum(Tensor dy, Tensor x, Tensor(a!) ws) -> ()");
@@ -1287,6 +1302,8 @@ TORCH_LIBRARY(dpa, m) {
 
 TORCH_LIBRARY_IMPL(dpa, CompositeExplicitAutograd, m) {
   m.impl("wgrad2_set_stages", [](int64_t s) { dpa::wgrad2_set_stages((int)s); });
+  m.impl("scale_unless", scale_unless);
+  m.impl("wgrad2_force_splits", [](int64_t s) { dpa::wgrad2_force_splits((int)s); });
   // Reads and clears the runtime's sticky "last error" of this thread (a stream capture that was invalidated leaves
   // one behind, and the next launch's error check would report it as its own). Returns the error code read.
   m.impl("clear_last_error", []() -> int64_t { return (int64_t)hipGetLastError(); });

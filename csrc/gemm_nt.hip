@@ -185,7 +185,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
   const int q = lane >> 4, l15 = lane & 15;
   const int nk = p.K / 64;
 
-  const rsrc_t rsA = make_rsrc(p.a, p.a_bytes);
   const rsrc_t rsB = make_rsrc(p.b, p.b_bytes);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
 
@@ -272,6 +271,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     const bool live = g >= 0 && g < p.ngroups;
     return make_rsrc(reinterpret_cast<const void*>(p.w_ptrs[live ? g : 0]), live ? p.b_bytes : 0u);
   };
+  // The A operand is addressed per output tile: the descriptor starts at the tile's first row and covers its 256
+  // rows (fewer at the bottom edge: rows past M read zeros), so offsets stay below 2^30 bytes however tall A is
+  // (dlogits [65536, 50304] of the head's input gradient is 6.6 GB). One 64-bit multiply-add per tile.
+  auto a_rsrc = [&](int m0) -> rsrc_t {
+    int rows = p.M - m0;
+    if (rows > 256) rows = 256;
+    if (rows < 1) rows = 1;
+    return make_rsrc(static_cast<const char*>(p.a) + (long long)m0 * p.lda * 2,
+                     (unsigned)((rows - 1) * (long long)p.lda * 2 + (long long)p.K * 2));
+  };
+  rsrc_t rsA_cur = a_rsrc(cur_m0), rsA_nxt = have_nxt ? a_rsrc(nxt_m0) : rsA_cur;
   rsrc_t rsB_cur = rsB, rsB_nxt = rsB;
   if (GROUPED) {
     rsB_cur = group_rsrc(cur_m0);
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
     const bool over = kk >= nk;
     const unsigned k = (unsigned)(over ? kk - nk : kk) * 128u;
     unsigned base;
-    if (IS_A) base = (unsigned)(over ? nxt_m0 : cur_m0) * (unsigned)p.lda * 2u + (HALF ? aStepMh : 0u) + k;
+    if (IS_A) base = (HALF ? aStepMh : 0u) + k;
     else base = ((unsigned)(over ? nxt_n0 : cur_n0) >> (kPair ? 1 : 0)) * (unsigned)p.ldb * 2u + (HALF ? bStepNh : 0u) + k;
     if (over && !have_nxt) base = kOob;
     const unsigned ldsu = copy * kCopy + ((IS_A ? 0 : 2) + HALF) * kUnit;
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       asm volatile("" ::"v"(v0), "v"(v1), "s"(ldsu));
       return;
     }
-    const rsrc_t rs = IS_A ? rsA : (GROUPED ? (over ? rsB_nxt : rsB_cur) : rsB);
+    const rsrc_t rs = IS_A ? (over ? rsA_nxt : rsA_cur) : (GROUPED ? (over ? rsB_nxt : rsB_cur) : rsB);
     dma16(pieceLds0 + ldsu, v0, rs);
     dma16(pieceLds1 + ldsu, v1, rs);
   };
@@ -822,6 +832,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
       nxt_m0 = t2.m0;
       nxt_n0 = t2.n0;
     }
+    rsA_cur = rsA_nxt;
+    if (have_nxt) rsA_nxt = a_rsrc(nxt_m0);
     if (GROUPED) {
       rsB_cur = rsB_nxt;
       if (have_nxt) rsB_nxt = group_rsrc(nxt_m0);
@@ -886,7 +898,7 @@ int g_gemm_nt_variant = 0;   // benchmark knob: bit 0 = one barrier per phase, b
 void gemm_nt_set_variant(int v) { g_gemm_nt_variant = v; }
 
 long long gemm_nt_rows_per_launch(const GemmNtArgs& a, int epi) {
-  long long ldm = a.lda > a.ldc ? a.lda : a.ldc;
+  long long ldm = a.ldc;       // the A operand is addressed per tile (any height); c and the auxiliary tensors by row offset
   if ((a.aux_in != nullptr || a.aux_out != nullptr) && a.ld_aux > ldm) ldm = a.ld_aux;
   long long align = 256;
   if (epi == kEpiRope && a.rope_T > 0) align = a.rope_T % 256 == 0 ? a.rope_T : 2ll * a.rope_T;   // rope_T % 128 == 0

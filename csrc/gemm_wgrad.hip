@@ -14,7 +14,8 @@
 // Three kernels, fastest applicable one first:
 //  * wgrad3_kernel: 256x256 output tile, 4 waves of 128x128 (accumulators in AGPRs), one workgroup
 //    per CU, two 64 KiB LDS stages filled by LDS-DMA from inline assembly; per-split fp32 slabs;
-//    optional bias gradient from the dY fragments. Needs N % 256 == 0 and K % 256 == 0.
+//    optional bias gradient from the dY fragments. Needs N % 128 == 0 (a half-empty last row of tiles is
+//    allowed) and K % 256 == 0.
 //  * wgrad2_kernel: 128x256 tile, 4 waves of 128x64, single 48 KiB LDS buffer filled by LDS-DMA,
 //    two workgroups per CU hide each other's transfer latency. Needs K % 256 == 0, M % 64 == 0.
 //  * wgrad_kernel: 128x128 tile, register-staged double buffer, fp32 workspace with float atomics
@@ -25,6 +26,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "mfma_tiles.h"
+#include "host_logic.h"
 
 namespace dpa {
 
@@ -32,6 +34,13 @@ namespace dpa {
 // 2 = no LDS-DMA after the first tile, 3 = LDS-DMA only (no fragment reads, no MFMAs)
 #ifndef DPA_WG3_ABLATE
 #define DPA_WG3_ABLATE 0
+#endif
+// 1 = ring of four 32-token LDS slots with fragments requested one token step ahead; 0 = two 64-token stages
+#ifndef DPA_WG3_RING
+#define DPA_WG3_RING 1
+#endif
+#ifndef DPA_WG3_SLOTS
+#define DPA_WG3_SLOTS 5     // ring slots of 32 KiB (4 or 5: 128 or 160 KiB of LDS)
 #endif
 
 constexpr int kWgTile = 128;   // output tile edge
@@ -145,6 +154,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const bf16_t* __restrict__ d
 // reproducible); the finishing pass sums the slabs.
 // ------------------------------------------------------------------------------------------
 constexpr int kW2N = 128, kW2K = 256;
+constexpr int kWg3Lds = (DPA_WG3_RING && DPA_WG3_SLOTS == 5) ? 163840 : 131072;
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
@@ -248,7 +262,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                                                         float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                         int M, int N, int K, long long ldy, long long ldx,
                                                         int splits, int mper, const long long* __restrict__ seg_start = nullptr,
-                                                        const long long* __restrict__ seg_rows = nullptr, int nseg = 1) {
+                                                        const long long* __restrict__ seg_rows = nullptr, int nseg = 1,
+                                                        WgradWalk walk = WgradWalk(), void* direct = nullptr,
+                                                        int direct_bf16 = 0) {
   constexpr int SUB = 64 * 128 * 2;  // 16 KiB
   constexpr int STAGE = 4 * SUB;     // 64 KiB: two dY sub-tiles + two X sub-tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,13 +274,28 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // XCD holds (about) all output tiles of ONE token split: those workgroups walk the same token
   // stages at the same pace and share every dY / X stage through that L2 instead of each pulling
   // its own copy over the fabric (5-8 % on the GPT-2-124M shapes).
-  const int ntile = (N / 256) * tiles_k;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  int split = id / ntile;
-  const int tile = id % ntile;
-  const int tn = tile / tiles_k, tk = tile % tiles_k;
+  const int ntile = ((N + 255) / 256) * tiles_k;   // N % 128 == 0: the last row of tiles may be half empty
+  int split, tile;
+  bool atomic_out = GROUPED;
+  if (ACCUM) {
+    // accumulation into one fp32 result across launches: see WgradWalk
+    const WgradItem it = walk.at(blockIdx.x);
+    if (it.parts == 0) return;
+    tile = it.tile;
+    split = it.part;
+    atomic_out = it.parts > 1;
+    mper = (M / 64 + it.parts - 1) / it.parts * 64;
+  } else {
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    split = id / ntile;
+    tile = id % ntile;
+  }
+  int tn, tk;
+  wgrad_tile_coord(tile, (N + 255) / 256, tiles_k, tn, tk);
   const int n0 = tn * 256, k0 = tk * 256;
   const int wn = wave >> 1, wk = wave & 1;
+  const int ycol1 = n0 + 128 < N ? 128 : 0;   // half-empty last tile: the second dY sub-tile re-reads the first (never stored)
+  const bool rows_ok = n0 + 128 * wn < N;     // this wave's 128 output rows exist
   int seg = 0, m_begin = 0, m_end = 0;
   // grouped mode: this workgroup's chunks [c_lo, c_hi) of the chunk numbering that runs through the segments;
   // c0 = number of the first chunk of segment `seg`, seg_nch = chunks of that segment
@@ -319,11 +350,91 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   int bias_cnt = bias_me;      // token steps until this wave's next turn
 
   const unsigned lds0 = (unsigned)(size_t)(dma_lptr_t)smem;
+#if DPA_WG3_RING
+  // Ring of four 32-token slots (32 KiB each: two dY and two X sub-tiles of 32 x 128). Slot t+1 is published (its
+  // transfers waited for, then the workgroup barrier) in the MIDDLE of the work on slot t, and the operand
+  // fragments of a token step are requested one step ahead, across slots: the MFMA stream never waits for a
+  // slot to land or for a first LDS read. Transfers run three slots ahead (up to 96 KiB in flight).
+  constexpr int RSUB = 32 * 128 * 2, RSLOT = 4 * RSUB, NSLOT = DPA_WG3_SLOTS, AHEAD = NSLOT - 1;
+  const int nst = 2 * ntiles;      // 32-token stages
+  auto issue_sub = [&](int t, int q) {          // sub-tile q of stage t: dY columns 0 / 128, X columns 0 / 128
+    const unsigned base = lds0 + (t % NSLOT) * RSLOT + q * RSUB;
+    if (t > nst - 1) t = nst - 1;              // past the end: the last stage again (never read), so that the
+    const long long m = m_begin + (long long)t * 32;   // count of transfers in flight is the same in every iteration
+    if (q < 2) dma_rows32x128_asm(dy + m * ldy + n0 + ycol1 * q, ldy, 128, base, wave, lane);
+    else dma_rows32x128_asm(x + m * ldx + k0 + 128 * (q - 2), ldx, 128, base, wave, lane);
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_sub(t, q);
+  };
+  auto frag_a = [&](int t, int s, int i) { return tr_frag<128>(smem + (t % NSLOT) * RSLOT + wn * RSUB, 0, s, i, lane); };
+  auto frag_b = [&](int t, int s, int j) { return tr_frag<128>(smem + (t % NSLOT) * RSLOT + (2 + wk) * RSUB, 0, s, j, lane); };
+  auto bias_step = [&](const bfrag (&a)[4]) {
+    if (BIAS) {
+      if (bias_cnt == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 v = __builtin_bit_cast(u32x4, a[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[i] += lo_bf16(v[e]) + hi_bf16(v[e]);
+        }
+        bias_cnt = bias_q;
+      }
+      --bias_cnt;
+    }
+  };
+  // One token step: the 16 MFMAs on (a, b) in four groups of four; behind group g go the reads of one A and one B
+  // fragment of the next step (into an, bn) and, with DMA, the transfer of sub-tile g of stage `tdma`. The
+  // sched_group_barrier sequence pins that order (left alone the scheduler sinks every read down to its first use).
+  auto step = [&](const bfrag (&a)[4], const bfrag (&b)[4], bfrag (&an)[4], bfrag (&bn)[4], int tn, int sn, bool dma,
+                  int tdma) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[g][j] = mfma32(a[g], b[j], acc[g][j]);
+      // read in the order of first use by the next step: a0 b0 | b1 b2 | b3 a1 | a2 a3
+      if (g == 0) { an[0] = frag_a(tn, sn, 0); bn[0] = frag_b(tn, sn, 0); }
+      if (g == 1) { bn[1] = frag_b(tn, sn, 1); bn[2] = frag_b(tn, sn, 2); }
+      if (g == 2) { bn[3] = frag_b(tn, sn, 3); an[1] = frag_a(tn, sn, 1); }
+      if (g == 3) { an[2] = frag_a(tn, sn, 2); an[3] = frag_a(tn, sn, 3); }
+      if (dma) issue_sub(tdma, g);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+    }
+    bias_step(a);
+  };
+  if (nst > 0) {
+    bfrag a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) issue(i);
+    wait_vm<8 * (AHEAD - 1)>();                         // stage 0 (8 transfers per wave and stage, retired in order)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a0[i] = frag_a(0, 0, i);
+      b0[i] = frag_b(0, 0, i);
+    }
+    for (int t = 0; t < nst; ++t) {
+      step(a0, b0, a1, b1, t, 1, false, 0);
+      // stage t+1 has landed; the barrier also proves that every wave is done reading slot t-1, which stage t+3 overwrites
+      wait_vm<8 * (AHEAD - 2)>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      step(a1, b1, a0, b0, t + 1, 0, true, t + AHEAD);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transfers past the end
+  }
+#else
   auto issue = [&](int t, int stage) {
     const long long m = m_begin + (long long)t * 64;
     const unsigned base = lds0 + stage * STAGE;
     dma_rows64x128_asm(dy + m * ldy + n0, ldy, 128, base, wave, lane);
-    dma_rows64x128_asm(dy + m * ldy + n0 + 128, ldy, 128, base + SUB, wave, lane);
+    dma_rows64x128_asm(dy + m * ldy + n0 + ycol1, ldy, 128, base + SUB, wave, lane);
     dma_rows64x128_asm(x + m * ldx + k0, ldx, 128, base + 2 * SUB, wave, lane);
     dma_rows64x128_asm(x + m * ldx + k0 + 128, ldx, 128, base + 3 * SUB, wave, lane);
   };
@@ -369,16 +480,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       }
     }
   }
+#endif
   if (BIAS) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      if (hh == 0) bias_slabs[((long long)split * bias_q + bias_me) * N + n0 + 128 * wn + 32 * i + (lane & 31)] = tot;
+      if (hh == 0 && rows_ok) bias_slabs[((long long)split * bias_q + bias_me) * N + n0 + 128 * wn + 32 * i + (lane & 31)] = tot;
     }
   }
 
   float* out = slabs + (GROUPED ? (long long)seg * N * K : (ACCUM ? 0 : (long long)split * N * K));
   const int col = lane & 31;
+  if (rows_ok) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -389,10 +502,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const int n = n0 + 128 * wn + 32 * i + acc_row(r, hh);
         float* p = out + (long long)n * K + kk;
         if (GROUPED) unsafeAtomicAdd(p, acc[i][j][r]);
-        else if (ACCUM) *p += acc[i][j][r];
-        else *p = acc[i][j][r];
+        else if (ACCUM) {
+          if (atomic_out) unsafeAtomicAdd(p, acc[i][j][r]);
+          else *p += acc[i][j][r];
+        } else if (direct != nullptr) {
+          // one split: the gradient itself is the destination (bf16 or fp32, added to), no slab and no fold
+          const long long o = (long long)n * K + kk;
+          if (direct_bf16) {
+            bf16_t* d = (bf16_t*)direct + o;
+            *d = f32_to_bf16(bf16_to_f32(*d) + acc[i][j][r]);
+          } else {
+            ((float*)direct)[o] += acc[i][j][r];
+          }
+        } else *p = acc[i][j][r];
       }
     }
+  }
   if (!GROUPED) break;
   // next segment; every wave is done with the LDS stages before the next range's first transfer lands in them
   c0 += seg_nch;
@@ -492,12 +617,16 @@ bool wgrad2_ok(int M, int N, int K) { return M % 64 == 0 && M >= 64 && N % 8 == 
 int g_wgrad2_stages = 4;   // 4 = 256x256 kernel where the shape allows, else (and with 1) the 128x256 kernel (benchmark knob)
 
 static bool use_wgrad3(int M, int N, int K) {
-  return g_wgrad2_stages == 4 && N % 256 == 0 && K % 256 == 0 && M >= 1024;
+  return g_wgrad2_stages == 4 && N % 128 == 0 && K % 256 == 0 && M >= 1024;
 }
 
+int g_wgrad2_force_splits = 0;   // benchmark knob: > 0 overrides the split count of the 256x256 kernel
+void wgrad2_force_splits(int s) { g_wgrad2_force_splits = s; }
+
 int wgrad2_splits(int M, int N, int K) {
+  if (use_wgrad3(M, N, K) && g_wgrad2_force_splits > 0) return g_wgrad2_force_splits;
   if (use_wgrad3(M, N, K)) {
-    const int t3 = (N / 256) * (K / 256);
+    const int t3 = ((N + 255) / 256) * (K / 256);
     int s3 = 256 / t3;                   // one workgroup per CU
     if (s3 > M / 512) s3 = M / 512;      // at least 8 LDS tiles per workgroup
     if (s3 > 64) s3 = 64;
@@ -520,27 +649,36 @@ bool wgrad2_fuses_bias(int M, int N, int K) { return use_wgrad3(M, N, K); }
 // rows of the fp32 [rows, N] partial bias sums the fused form writes (every one is written: sum them all)
 int wgrad2_bias_slabs(int M, int N, int K) { return wgrad2_splits(M, N, K) * 2 * (K / 256); }
 
+bool wgrad2_direct_ok(int M, int N, int K) { return use_wgrad3(M, N, K) && wgrad2_splits(M, N, K) == 1; }
+
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
-                 int splits, hipStream_t st, float* bias_slabs) {
+                 int splits, hipStream_t st, float* bias_slabs, void* direct, bool direct_bf16) {
   if (M == 0) return;
   const int sp = splits > 0 ? splits : 1;
   int mper = (M / 64 + sp - 1) / sp * 64;
   if (use_wgrad3(M, N, K)) {
     static bool attr3 = false;
     if (!attr3) {
-      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWg3Lds);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWg3Lds);
+      (void)hipFuncSetAttribute((const void*)wgrad3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWg3Lds);
       attr3 = true;
     }
-    const dim3 grid3((N / 256) * (K / 256) * sp), block3(256);
+    const int tiles = ((N + 255) / 256) * (K / 256);
+    const dim3 grid3(tiles * sp), block3(256);
 #define DPA_W3(ACC, BI)                                                                                          \
-  hipLaunchKernelGGL((wgrad3_kernel<ACC, BI>), grid3, block3, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, ws, \
-                     bias_slabs, M, N, K, ldy, ldx, sp, mper)
+  hipLaunchKernelGGL((wgrad3_kernel<ACC, BI>), grid3, block3, kWg3Lds, st, (const bf16_t*)dy, (const bf16_t*)x, ws, \
+                     bias_slabs, M, N, K, ldy, ldx, sp, mper, (const long long*)nullptr, (const long long*)nullptr, 1, \
+                     WgradWalk(), splits == 1 ? direct : nullptr, direct_bf16 ? 1 : 0)
     if (splits > 0) {
       if (bias_slabs != nullptr) DPA_W3(false, true); else DPA_W3(false, false);
     } else {
-      DPA_W3(true, false);
+      WgradWalk walk;
+      walk.tiles = tiles;
+      walk.max_parts = M / 2048 < 1 ? 1 : (M / 2048 > 8 ? 8 : M / 2048);
+      hipLaunchKernelGGL((wgrad3_kernel<true, false>), dim3(walk.grid()), block3, kWg3Lds, st, (const bf16_t*)dy,
+                         (const bf16_t*)x, ws, (float*)nullptr, M, N, K, ldy, ldx, 1, mper, (const long long*)nullptr,
+                         (const long long*)nullptr, 1, walk);
     }
 #undef DPA_W3
     return;
@@ -565,7 +703,7 @@ void wgrad3_grouped(const void* dy, const void* x, float* out, const long long* 
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)wgrad3_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              131072);
+                              kWg3Lds);
     attr = true;
   }
   // one workgroup per CU: row shares so that tiles * shares fills the 256 CUs once (at least 1024 rows per share)
@@ -575,7 +713,7 @@ void wgrad3_grouped(const void* dy, const void* x, float* out, const long long* 
   if (items > max_items) items = max_items;
   if (items < 1) items = 1;
   const dim3 grid(tiles * items), block(256);
-  hipLaunchKernelGGL((wgrad3_kernel<false, false, true>), grid, block, 131072, st, (const bf16_t*)dy, (const bf16_t*)x, out,
+  hipLaunchKernelGGL((wgrad3_kernel<false, false, true>), grid, block, kWg3Lds, st, (const bf16_t*)dy, (const bf16_t*)x, out,
                      (float*)nullptr, rows, N, K, ldy, ldx, 1, kGroupedChunk, seg_start, seg_rows, nseg);
 }
 

@@ -113,7 +113,10 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 // splits == 0: one pass that adds into ws[N*K].
 bool wgrad2_ok(int M, int N, int K);
 int wgrad2_splits(int M, int N, int K);
+// x (n elements, n % 8 == 0, 16-byte aligned) *= g[0] / expected unless g[0] == expected
+void scale_unless(void* x, long long n, bool is_bf16, const float* g, float expected, hipStream_t st);
 void wgrad2_set_stages(int s);
+void wgrad2_force_splits(int s);
 // bias_slabs (optional, only when wgrad2_fuses_bias(M, N, K) and splits > 0): fp32 [wgrad2_bias_slabs(M, N, K), N]
 // receiving partial column sums of dy (their sum is the bias gradient), produced inside the same kernel.
 bool wgrad2_fuses_bias(int M, int N, int K);
@@ -125,7 +128,11 @@ bool wgrad3_grouped_ok(long long rows, int N, int K);
 void wgrad3_grouped(const void* dy, const void* x, float* out, const long long* seg_start, const long long* seg_rows,
                     int nseg, int rows, int N, int K, long long ldy, long long ldx, hipStream_t st);
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
-                 int splits, hipStream_t st, float* bias_slabs = nullptr);
+                 int splits, hipStream_t st, float* bias_slabs = nullptr, void* direct = nullptr,
+                 bool direct_bf16 = false);
+// wgrad2_direct_ok: the product runs as one split of the 256 x 256 kernel, which then takes `direct` (bf16 or fp32
+// [N, K], added to in place) instead of writing a slab to ws
+bool wgrad2_direct_ok(int M, int N, int K);
 void wgrad_finish(const float* ws, void* out, long long n, int nslabs, bool accumulate, bool out_bf16,
                   hipStream_t st);
 // out_g (+)= ws[g] for `count` destinations of n elements each, given by device addresses.

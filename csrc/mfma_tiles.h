@@ -158,4 +158,30 @@ __device__ __forceinline__ void dma_rows64x128_asm(const bf16_t* g, long long ld
   }
 }
 
+// The same transfer for a [32 rows][128 cols] tile (8 pieces of 4 rows, 2 per wave). No "memory" clobber: the
+// compiler may move its own LDS reads across the statement (they touch other ring slots; the ordering that
+// matters is made by the caller's s_waitcnt + barrier statements, which do carry the clobber), so that a
+// transfer can sit in the middle of an MFMA / LDS-read stream.
+__device__ __forceinline__ void dma_rows32x128_asm(const bf16_t* g, long long ld, int col_limit, unsigned lds_addr,
+                                                   int wave, int lane) {
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc) {
+    const int piece = wave * 2 + pc;
+    const int row = piece * 4 + (lane >> 4);
+    int chunk = swz<128>(row, lane & 15);
+    if (chunk * 8 >= col_limit) chunk = 0;
+    const bf16_t* src = g + (long long)row * ld + chunk * 8;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + piece * 1024);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst));
+  }
+}
+
 }  // namespace dpa

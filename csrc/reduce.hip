@@ -52,6 +52,34 @@ void colsum(const void* x, float* out, long long M, int N, long long ld, bool is
     hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)x, out, M, N, ld, (int)rpb);
 }
 
+// x *= g / expected, unless the two are equal (then every thread leaves after reading g: no pass over x). The fused
+// head loss writes its gradients already multiplied by the factor the caller said the loss would be scaled by; its
+// backward only has to correct them when the incoming gradient turns out to be something else.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_unless_kernel(T* __restrict__ x, long long nvec, const float* __restrict__ g,
+                                                           float expected) {
+  const float r = g[0] / expected;
+  if (r == 1.0f) return;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= r;
+    store8(x + i * 8, v);
+  }
+}
+
+void scale_unless(void* x, long long n, bool is_bf16, const float* g, float expected, hipStream_t st) {
+  const long long nvec = n >> 3;
+  if (nvec == 0) return;
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (is_bf16)
+    hipLaunchKernelGGL((scale_unless_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (bf16_t*)x, nvec, g, expected);
+  else
+    hipLaunchKernelGGL((scale_unless_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (float*)x, nvec, g, expected);
+}
+
 // Benchmark aid: `blocks` workgroups that each hold a CU busy for about `usec` microseconds (a stand-in
 // for a collective's kernels when the effect of lost CUs on the compute kernels is measured on one GPU).
 // Every wave leaves after the deadline or after a bounded number of polls, whichever comes first.

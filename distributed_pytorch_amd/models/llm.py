@@ -667,6 +667,9 @@ class LLM(nn.Module):
         self.VAL_RUN = False
         self.materialize_logits = False   # True: also return [B, T, V] logits when targets are given
         self.loss_chunk_rows = int(os.environ.get("DPA_LOSS_CHUNK", "65536"))
+        # the factor the training loop multiplies the loss by before backward (1 / accumulation steps): the fused
+        # head loss writes its gradients with it applied (a different incoming gradient is still honoured)
+        self.loss_grad_scale = 1.0
         # set by a data-parallel engine built with vocab_parallel=True: (process group,) of the ranks the
         # vocabulary dimension of the head is split over during training
         self.vocab_parallel = None
@@ -820,7 +823,8 @@ class LLM(nn.Module):
                 main_loss = ops.vocab_parallel_linear_cross_entropy(x, wte, targets, group=self.vocab_parallel[0],
                                                                     chunk_rows=self.loss_chunk_rows)
             else:
-                main_loss = ops.linear_cross_entropy(x, wte, targets, chunk_rows=self.loss_chunk_rows)
+                main_loss = ops.linear_cross_entropy(x, wte, targets, chunk_rows=self.loss_chunk_rows,
+                                                     expected_grad=self.loss_grad_scale if self.training else 1.0)
             loss = main_loss + total_aux / cfg.n_layer
         else:
             logits = ops.linear(x[:, -1:, :], wte)   # a slice, not a list index: no host-built index tensor

@@ -36,15 +36,11 @@ def wgrad2_supported(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0)
 
 
-# Output sizes from which the library's split-K kernels overtake the hand-written weight-gradient
-# kernels (measured on MI355X, benchmarks/wgrad_shapes_bench.py: own kernels win up to 4.2 M output
-# elements, the library from 12.6 M; a 256x256 tiling of a large output no longer divides evenly
-# over 256 CUs and the split-M advantage is gone).
-LIBRARY_WGRAD_MIN_OUT = int(os.environ.get("DPA_LIBRARY_WGRAD_MIN_OUT", 8 * 1024 * 1024))
-
-
 def _library_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
-    return dy2.shape[1] * x2.shape[1] >= LIBRARY_WGRAD_MIN_OUT
+    """Weight gradients run on the own kernels at every size (the 256 x 256 kernel numbers its tiles in blocks per
+    XCD and writes a one-split product straight into the gradient: benchmarks/wgrad_shapes_bench.py); the library
+    serves them only under ``DPA_LIBRARY_GEMM=1``, the switch of the A/B comparisons."""
+    return os.environ.get("DPA_LIBRARY_GEMM", "0") == "1"
 
 
 def bias_grad(dy2: torch.Tensor) -> torch.Tensor:
@@ -56,8 +52,8 @@ def bias_grad(dy2: torch.Tensor) -> torch.Tensor:
 
 
 def weight_grad(dy2: torch.Tensor, x2: torch.Tensor, want_bias: bool, version: int = 0):
-    """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16. ``version``: 0 = fastest path for
-    the shape (library for very large outputs), 1 = register-staged kernel, 2 = LDS-DMA kernels."""
+    """(dw [N, K], dbias [N] | None) for dy2 [M, N], x2 [M, K] in bf16. ``version``: 0 = the kernel
+    picked for the shape, 1 = register-staged kernel, 2 = LDS-DMA kernels."""
     N, K = dy2.shape[1], x2.shape[1]
     if version == 0 and _library_wgrad(dy2, x2):
         return torch.mm(dy2.t(), x2), (bias_grad(dy2) if want_bias else None)

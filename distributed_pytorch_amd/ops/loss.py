@@ -8,8 +8,10 @@ logits with d(loss)/d(logits), so no fp32 probability tensor ever exists.
 the ``[B*T, V]`` logits: rows are processed in chunks; for each chunk the logits GEMM (the own NT
 MFMA kernel), the cross-entropy kernel (one read, one in-place write of the chunk) and (when
 training) the two gradient GEMMs ``dx = dlogits @ w`` and ``dw += dlogits^T @ x`` run back to
-back on one reused bf16 buffer, so only ``[chunk, V]`` ever exists and the backward pass only
-rescales the stored gradients by the incoming scalar. The chunk is far larger than any cache of
+back on one reused bf16 buffer, so only ``[chunk, V]`` ever exists. All three products are the own kernels
+(csrc/gemm_nt.hip; csrc/gemm_wgrad.hip with fp32 sums across the chunks). The cross-entropy kernel writes the
+gradient already multiplied by 1 / valid targets and by the factor the caller announces for the loss
+(``expected_grad``), so the backward pass has nothing left to do but check that factor. The chunk is far larger than any cache of
 the part (65536 x 50304 bf16 = 6.6 GB of the 288 GB): every pass over it is an HBM pass, and the
 chunk size is chosen for GEMM efficiency, not residency — measured per piece in
 benchmarks/lmhead_bench.py (2048-row chunks that would fit the 256 MB last-level cache cost 25 ms
@@ -78,85 +80,114 @@ def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int
     return F.cross_entropy(logits2.float(), targets1, ignore_index=ignore_index)
 
 
-_OWN_PIECE = 16384   # rows per launch of the own logits GEMM (16384 x 50304 bf16 = 1.6 GB, below its 2 GiB limit)
-
-
-def _own_logits_gemm(xc: torch.Tensor, w: torch.Tensor) -> bool:
+def _library_head() -> bool:
     import os
-    if os.environ.get("DPA_LIBRARY_GEMM", "0") == "1" or os.environ.get("DPA_LOSS_OWN_GEMM", "1") == "0" \
-            or not hasattr(ops(), "gemm_nt_into"):
-        return False
-    return bool(ops().gemm_nt_supported(xc, w, None, None))
+    return os.environ.get("DPA_LIBRARY_GEMM", "0") == "1" or os.environ.get("DPA_LOSS_OWN_GEMM", "1") == "0"
+
+
+def _head_plan(x: torch.Tensor, w: torch.Tensor):
+    """Which of the three products of the head run on the own kernels: (logits, dx, dw)."""
+    if x.dtype != torch.bfloat16 or _library_head() or not hasattr(ops(), "gemm_nt_into"):
+        return False, False, False
+    V, C = w.shape
+    probe = x[: min(x.shape[0], 16384)]
+    own_logits = bool(ops().gemm_nt_supported(probe, w, None, None))
+    # dx = dlogits [rows, V] @ w through the NT kernel on w^T [C, V]: contraction over the vocabulary
+    own_dx = V % 64 == 0 and V >= 128 and C % 16 == 0 and w.is_contiguous()
+    # dw += dlogits^T x on the 256 x 256 weight-gradient kernel, fp32 sums kept in the kernel's own walk over the tiles
+    own_dw = V % 128 == 0 and C % 256 == 0
+    return own_logits, own_dx, own_dw
 
 
 class _LinearXentFn(torch.autograd.Function):
+    """Row chunks of: logits GEMM -> cross-entropy kernel (one read, one in-place write of the chunk: loss, and
+    d loss / d logits already multiplied by 1 / valid targets and by the factor the caller announced for the loss)
+    -> dx GEMM -> dw GEMM (fp32 sums across the chunks). All three products are the own kernels; backward only
+    checks that the incoming gradient is the announced factor (``scale_unless``: no pass over dx / dw when it is)."""
+
     @staticmethod
-    def forward(ctx, x, w, targets, ignore_index, chunk_rows):
+    def forward(ctx, x, w, targets, ignore_index, chunk_rows, expected_grad):
         N, C = x.shape
         V = w.shape[0]
         need_dx = ctx.needs_input_grad[0]
         need_dw = ctx.needs_input_grad[1]
         train = need_dx or need_dw
         gs = _grad_scale(targets, ignore_index)
+        gs_grad = gs * expected_grad if expected_grad != 1.0 else gs
         loss_acc = torch.zeros((), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if need_dx else None
+        own_logits, own_dx, own_dw = _head_plan(x, w)
+        wt = None
+        if need_dx and own_dx:
+            from .linear import transposed_weight
+            wt = transposed_weight(w)
+        bf16 = x.dtype == torch.bfloat16
+        ws = torch.zeros(V, C, dtype=torch.float32, device=x.device) if (need_dw and bf16) else None
         dw = None
-        # weight gradient: per-chunk library GEMM (for a [V, C] output the library's large-tile
-        # kernels are at their best) accumulated across the row chunks in fp32
-        nchunks = (N + chunk_rows - 1) // chunk_rows
-        use_wg = need_dw and x.dtype == torch.bfloat16 and nchunks > 1
-        ws = torch.zeros(V, C, dtype=torch.float32, device=x.device) if use_wg else None
-        own_gemm = x.dtype == torch.bfloat16 and _own_logits_gemm(x[: min(_OWN_PIECE, N)], w)
         logits = torch.empty(min(chunk_rows, N), V, dtype=x.dtype, device=x.device)
         for r0 in range(0, N, chunk_rows):
             r1 = min(N, r0 + chunk_rows)
+            rows = r1 - r0
             xc = x[r0:r1]
-            lg = logits[: r1 - r0]
-            if own_gemm:
-                # the own NT kernel addresses at most 2 GiB per operand: the chunk is filled in row pieces
-                for p0 in range(0, r1 - r0, _OWN_PIECE):
-                    p1 = min(r1 - r0, p0 + _OWN_PIECE)
-                    if ops().gemm_nt_supported(xc[p0:p1], w, None, None):
-                        ops().gemm_nt_into(xc[p0:p1], w, lg[p0:p1])
-                    else:
-                        torch.mm(xc[p0:p1], w.t(), out=lg[p0:p1])
+            lg = logits[:rows]
+            if own_logits and ops().gemm_nt_supported(xc, w, None, None):
+                ops().gemm_nt_into(xc, w, lg)        # walks row ranges of the 6.6 GB chunk by itself
             else:
                 torch.mm(xc, w.t(), out=lg)
-            loss_rows = ops().xent_fused(lg, targets[r0:r1], gs, ignore_index, train)
+            loss_rows = ops().xent_fused(lg, targets[r0:r1], gs_grad, ignore_index, train)
             loss_acc += loss_rows.sum()
             if need_dx:
-                torch.mm(lg, w, out=dx[r0:r1])
+                if wt is not None and ops().gemm_nt_supported(lg, wt, None, None):
+                    ops().gemm_nt_into(lg, wt, dx[r0:r1])
+                else:
+                    torch.mm(lg, w, out=dx[r0:r1])
             if need_dw:
-                if use_wg:
-                    # bf16 operands, fp32 sum: the library GEMM reads and writes the accumulator itself
-                    torch.addmm(ws, lg.t(), xc, out_dtype=torch.float32, out=ws)
+                if ws is not None:
+                    m64 = rows // 64 * 64 if own_dw else 0
+                    if m64 >= 1024:
+                        ops().wgrad2_accum(lg[:m64], xc[:m64], ws)
+                    else:
+                        m64 = 0
+                    if m64 < rows:   # a ragged tail of fewer than 64 rows (or a tiny chunk)
+                        torch.addmm(ws, lg[m64:].t(), xc[m64:], out_dtype=torch.float32, out=ws)
                 elif dw is None:
                     dw = torch.mm(lg.t(), xc)
                 else:
                     dw.addmm_(lg.t(), xc)
-        if use_wg:
+        if ws is not None:
             dw = ws.to(x.dtype)
         ctx.save_for_backward(dx, dw)
-        return loss_acc * gs[0]
+        ctx.expected_grad = expected_grad
+        return loss_acc * gs[0]     # the loss carries 1 / valid targets only; expected_grad went into the gradients
 
     @staticmethod
     def backward(ctx, g):
         dx, dw = ctx.saved_tensors
-        if dx is not None:
-            dx = dx.mul_(g.to(dx.dtype))
-        if dw is not None:
-            dw = dw.mul_(g.to(dw.dtype))
-        return dx, dw, None, None, None
+        g32 = g.detach().float().reshape(1)
+        for t in (dx, dw):
+            if t is None:
+                continue
+            if t.is_cuda and t.numel() % 8 == 0 and t.is_contiguous() and t.data_ptr() % 16 == 0:
+                ops().scale_unless(t, g32, float(ctx.expected_grad))
+            else:
+                t.mul_((g32[0] / ctx.expected_grad).to(t.dtype))
+        return dx, dw, None, None, None, None
 
 
 def linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor,
-                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 65536) -> torch.Tensor:
-    """Mean cross-entropy of ``x @ w.T`` against ``targets`` (``x [N, C]``, ``w [V, C]``)."""
+                         ignore_index: int = IGNORE_INDEX, chunk_rows: int = 65536,
+                         expected_grad: float = 1.0) -> torch.Tensor:
+    """Mean cross-entropy of ``x @ w.T`` against ``targets`` (``x [N, C]``, ``w [V, C]``).
+
+    ``expected_grad``: the gradient the caller expects to send into this loss (1 / accumulation steps when the loss
+    is divided before ``backward``). The stored gradients are produced with that factor already applied; any other
+    incoming gradient is still honoured (one rescaling pass)."""
     x2 = x.reshape(-1, x.shape[-1])
     t1 = targets.reshape(-1)
     if use_hip(x2, w, t1) and x2.dtype == w.dtype and x2.dtype in (torch.bfloat16, torch.float32) \
             and w.shape[0] % 8 == 0:
-        return _LinearXentFn.apply(x2.contiguous(), w, t1.contiguous(), ignore_index, int(chunk_rows))
+        return _LinearXentFn.apply(x2.contiguous(), w, t1.contiguous(), ignore_index, int(chunk_rows),
+                                   float(expected_grad) if expected_grad else 1.0)
     return F.cross_entropy(F.linear(x2, w).float(), t1, ignore_index=ignore_index)
 
 

@@ -126,6 +126,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
 
     # ---- model + engine --------------------------------------------------------------------
     model = LLM(mc)
+    model.loss_grad_scale = 1.0 / grad_accum_steps     # every micro-batch loss is divided by this before backward
     total, active = model.get_num_params()
     say(f"total parameters = {total:,}, acitive parameters = {active:,}")
     flops_tok = model_flops_per_token(model, T)

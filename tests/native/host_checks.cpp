@@ -120,6 +120,75 @@ static void test_gemm_walk() {
       }
 }
 
+static void test_wgrad_tile_coord() {
+  // a bijection onto the tile grid, whatever the grid's shape
+  for (int tn : {1, 2, 3, 4, 5, 8, 9, 12, 24, 32, 33, 197})
+    for (int tk : {1, 2, 3, 7, 8, 9, 12, 16, 31, 32, 33}) {
+      std::vector<char> seen((size_t)tn * tk, 0);
+      for (int t = 0; t < tn * tk; ++t) {
+        int a = -1, b = -1;
+        dpa::wgrad_tile_coord(t, tn, tk, a, b);
+        CHECK(a >= 0 && a < tn && b >= 0 && b < tk);
+        if (a >= 0 && a < tn && b >= 0 && b < tk) {
+          CHECK(!seen[(size_t)a * tk + b]);
+          seen[(size_t)a * tk + b] = 1;
+        }
+      }
+    }
+  // narrow grids keep the row-major order; an 8 x 32 grid is cut into 4 x 8 blocks
+  int a, b;
+  dpa::wgrad_tile_coord(7, 12, 3, a, b);
+  CHECK(a == 2 && b == 1);
+  dpa::wgrad_tile_coord(31, 8, 32, a, b);
+  CHECK(a == 3 && b == 7);
+  dpa::wgrad_tile_coord(32, 8, 32, a, b);
+  CHECK(a == 0 && b == 8);
+}
+
+static void test_wgrad_walk() {
+  // every (tile, part) of the accumulating weight-gradient walk is visited exactly once, parts of a tile agree on
+  // their count, and a tile summed in parts never also has a whole-rows item
+  for (int tiles : {1, 3, 7, 8, 9, 36, 192, 255, 256, 257, 591, 1024, 1031})
+    for (int max_parts : {1, 2, 8})
+      for (int cus : {4, 32}) {
+        dpa::WgradWalk w;
+        w.tiles = tiles;
+        w.cus = cus;
+        w.max_parts = max_parts;
+        const int grid = w.grid();
+        CHECK(grid % 8 == 0 && grid >= tiles);
+        std::vector<int> parts(tiles, 0), seen(tiles, 0);
+        std::vector<std::vector<char>> hit(tiles);
+        for (int b = 0; b < grid; ++b) {
+          const dpa::WgradItem it = w.at(b);
+          if (it.parts == 0) continue;
+          CHECK(it.tile >= 0 && it.tile < tiles && it.parts >= 1 && it.parts <= max_parts && it.part >= 0 && it.part < it.parts);
+          if (it.tile < 0 || it.tile >= tiles) continue;
+          if (parts[it.tile] == 0) {
+            parts[it.tile] = it.parts;
+            hit[it.tile].assign(it.parts, 0);
+          }
+          CHECK(parts[it.tile] == it.parts);
+          if (parts[it.tile] == it.parts && it.part < it.parts) {
+            CHECK(!hit[it.tile][it.part]);
+            hit[it.tile][it.part] = 1;
+            ++seen[it.tile];
+          }
+        }
+        for (int t = 0; t < tiles; ++t) CHECK(parts[t] >= 1 && seen[t] == parts[t]);
+      }
+  // the head gradient of GPT-2 (197 x 3 tiles): two whole rounds and a third of thirds on every XCD
+  dpa::WgradWalk w;
+  w.tiles = 591;
+  w.max_parts = 8;
+  CHECK(w.grid() == 8 * 94);
+  for (int x = 0; x < 8; ++x) {
+    int lo, full, rest, parts;
+    w.range(x, lo, full, rest, parts);
+    CHECK(full == 64 && (rest == 9 || rest == 10) && parts == 3);
+  }
+}
+
 static void test_gemm_shapes() {
   using dpa::gemm_nt_shape_ok;
   CHECK(gemm_nt_shape_ok(65536, 2304, 768, 768, 768, 2304, 0, true));
@@ -169,6 +238,8 @@ int main(int argc, char** argv) {
   }
   test_token_stream(argv[1]);
   test_gemm_walk();
+  test_wgrad_tile_coord();
+  test_wgrad_walk();
   test_gemm_shapes();
   test_gemm_pair_shapes();
   if (g_failed) {
