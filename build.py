@@ -29,6 +29,10 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
+# Sources that textually include another source (rebuilt when that one changes).
+EXTRA_DEPS = {
+    "attention_wide.hip": ["attention.hip"],
+}
 
 
 def _hipcc() -> str:
@@ -73,7 +77,7 @@ def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
     for src in sorted(CSRC.glob("*.hip")):
         obj = OBJ / (src.stem + ".o")
         objs.append(obj)
-        if force or _stale(src, obj, headers):
+        if force or _stale(src, obj, headers + [CSRC / d for d in EXTRA_DEPS.get(src.name, [])]):
             cmd = [hipcc, *common, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
             if asm:
                 (ROOT / "build" / "asm").mkdir(parents=True, exist_ok=True)

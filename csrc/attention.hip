@@ -6,11 +6,15 @@
 //    plus one exchange between the two 32-lane halves, and the probability tile is already in
 //    the register layout the next MFMA wants as its B operand (O^T = V^T * P^T). Nothing but
 //    K and V ever goes through LDS in the forward.
-//  * K/V (forward, dQ) and Q/dO (dK/dV) tiles are staged global -> registers -> LDS with the
-//    loads of tile t+1 issued before the compute on tile t (double-buffered LDS, one barrier
-//    per tile). One XOR-swizzled LDS image serves both the row reads (ds_read_b128, operand A
-//    of the score products) and the transposed reads (ds_read_b64_tr_b16, operand A of the
-//    products that sum over keys/queries), conflict-free for both.
+//  * K/V (forward, dQ) and Q/dO (dK/dV) tiles go global -> LDS by LDS-DMA (buffer_load ... lds issued
+//    from inline assembly: no staging registers), the transfer of tile t+1 issued before the compute
+//    on tile t (double-buffered LDS, one s_waitcnt vmcnt(0) + barrier per tile). The XOR swizzle of
+//    the LDS image is applied on the global side of the transfer; one image serves both the row reads
+//    (ds_read_b128, operand A of the score products) and the transposed reads (ds_read_b64_tr_b16,
+//    operand A of the products that sum over keys/queries), conflict-free for both.
+//  * Key width DK and value width DV are separate template parameters: (64, 64) and (128, 128) for
+//    ordinary heads, (128, 64) and (256, 128) for latent attention with decoupled rotary keys (built in
+//    csrc/attention_wide.hip). Wide keys read their operand fragments in batches of 8 K-steps.
 //  * GQA is native: a query head reads the K/V head of its group directly (no repeat), and
 //    the dK/dV kernel accumulates over the query heads of the group in registers.
 //  * Backward is split in two kernels so no cross-workgroup reduction (atomics) is needed:
@@ -259,9 +263,10 @@ __device__ __forceinline__ float fwd_exp2(float x) { return DPA_ATTN_ABLATE ? x 
 // Probabilities up to ~1e9 instead of <= 1 cost nothing in accuracy: fp32 sums and the bf16 P operand
 // have the same relative precision at any magnitude.
 // ------------------------------------------------------------------------------------------
-template <int HS, bool DROP>
+template <int DK, int DV, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
+  constexpr int NK = DK / 16, ND = DV / 32, KTILE = 64 * DK * 2, VTILE = 64 * DV * 2, STAGE = KTILE + VTILE;
+  constexpr int KCH = NK > 8 ? 8 : NK;   // K fragments requested together (wide keys: in two or more batches)
   constexpr int KSUB = 2;   // head size 64: 32-key sub-tiles whose fragments are in registers together
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -279,20 +284,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     Tk = n < p.Tq ? p.Tq : (n > p.Tk ? p.Tk : n);
   }
   const int q0 = qt * 128, off = Tk - p.Tq;
-  const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
-  const rsrc_t krs = make_rsrc((const bf16_t*)p.k + b * p.k_bs + kvh * HS);
-  const rsrc_t vrs = make_rsrc((const bf16_t*)p.v + b * p.v_bs + kvh * HS);
+  const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * DK;
+  const rsrc_t krs = make_rsrc((const bf16_t*)p.k + b * p.k_bs + kvh * DK);
+  const rsrc_t vrs = make_rsrc((const bf16_t*)p.v + b * p.v_bs + kvh * DV);
 
   int kv_end = q0 + 128 + off;
   if (kv_end > Tk) kv_end = Tk;
   const int ntiles = (kv_end + 63) / 64;
   const int wave_qmax = q0 + wave * 32 + 31;
 
-  TileDma<HS> kd, vd;
+  TileDma<DK> kd;
+  TileDma<DV> vd;
   kd.init(p.k_ts, wave, lane);
   vd.init(p.v_ts, wave, lane);
   kd.issue(krs, 0, Tk, lds0);
-  vd.issue(vrs, 0, Tk, lds0 + TILE);
+  vd.issue(vrs, 0, Tk, lds0 + KTILE);
 
   const float c = p.scale * kLog2e;
   const int qrow = q0 + wave * 32 + r;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
 #ifdef DPA_ATTN_TRACE
   __shared__ unsigned trace_s[4][16][7];
-  const bool tracing = blockIdx.x == 300 && HS == 64;   // a workgroup of the first batch with all 16 tiles
+  const bool tracing = blockIdx.x == 300 && DK == 64;   // a workgroup of the first batch with all 16 tiles
   if (tracing) for (int i = tid; i < 4 * 16 * 7; i += 256) (&trace_s[0][0][0])[i] = 0u;
 #endif
   for (int t = 0; t < ntiles; ++t) {
@@ -326,15 +332,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __syncthreads();   // tile t has landed for every wave; every wave is done with tile t - 1's buffer
     DPA_ATR(1);
     if (t + 1 < ntiles) {
-      const unsigned nb = lds0 + ((t + 1) & 1) * 2 * TILE;
+      const unsigned nb = lds0 + ((t + 1) & 1) * STAGE;
       kd.issue(krs, (t + 1) * 64, Tk, nb);
-      vd.issue(vrs, (t + 1) * 64, Tk, nb + TILE);
+      vd.issue(vrs, (t + 1) * 64, Tk, nb + KTILE);
     }
     DPA_ATR(2);
-    const char* kb = smem + (t & 1) * 2 * TILE;
-    const char* vb = kb + TILE;
+    const char* kb = smem + (t & 1) * STAGE;
+    const char* vb = kb + KTILE;
     const int kv0 = t * 64;
-    if constexpr (HS == 64) {
+    if constexpr (DK == 64 && DV == 64) {
     // Head size 64: both 32-key sub-tiles of the tile together (3 waves per SIMD fit; measured 4 % faster than
     // one sub-tile at a time).
     if (kv0 <= wave_qmax + off) {  // wave-uniform: some key of this tile is visible to the wave
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
           for (int u = 0; u < KSUB; ++u)
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) kf[u][ks] = row_frag<HS>(kb, (sb + u) * 32 + r, ks, hh);
+            for (int ks = 0; ks < NK; ++ks) kf[u][ks] = row_frag<DK>(kb, (sb + u) * 32 + r, ks, hh);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < KSUB; ++u) {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<HS>(vb, u * 32, s2, dt, lane);
+          for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<DV>(vb, u * 32, s2, dt, lane);
       __builtin_amdgcn_sched_barrier(0);
       float rs = 0.f;
 #pragma unroll
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-              for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<HS>(vb, (sb + u) * 32, s2, dt, lane);
+              for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<DV>(vb, (sb + u) * 32, s2, dt, lane);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -464,21 +470,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
       const int ks0 = kv0 + sub * 32;
-      const char* ksub = kb + sub * (32 * HS * 2);
-      const char* vsub = vb + sub * (32 * HS * 2);
+      const char* ksub = kb + sub * (32 * DK * 2);
+      const char* vsub = vb + sub * (32 * DV * 2);
       const bool mk = (ks0 + 31 > wq0) || (ks0 + 32 > Tk);
       // s = scores - m, from the accumulator `init`. The K fragments are all requested before the
       // first MFMA: a read issued right before its MFMA, which is the compiler's pressure-minimising
       // order, exposes the LDS latency once per MFMA.
       f32x16 s;
       auto scores = [&](const f32x16& init) {
-        bfrag kf[NK];
+        s = init;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) kf[ks] = row_frag<HS>(ksub, r, ks, hh);
-        __builtin_amdgcn_sched_barrier(0);
-        s = mfma32(kf[0], qf[0], init);
+        for (int k0 = 0; k0 < NK; k0 += KCH) {
+          bfrag kf[KCH];
 #pragma unroll
-        for (int ks = 1; ks < NK; ++ks) s = mfma32(kf[ks], qf[ks], s);
+          for (int ks = 0; ks < KCH; ++ks) kf[ks] = row_frag<DK>(ksub, r, k0 + ks, hh);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < KCH; ++ks) s = mfma32(kf[ks], qf[k0 + ks], s);
+        }
         if (mk) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) vf[s2][dt] = tr_frag<HS>(vsub, 0, s2, dt, lane);
+        for (int dt = 0; dt < ND; ++dt) vf[s2][dt] = tr_frag<DV>(vsub, 0, s2, dt, lane);
       __builtin_amdgcn_sched_barrier(0);
       float rs = 0.f;
 #pragma unroll
@@ -550,8 +559,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   if (hh == 0 && qrow < p.Tq)
     p.lse[((long long)b * p.nh + h) * p.Tq + qrow] = (m + __builtin_amdgcn_logf(l)) * (1.f / kLog2e);
   __syncthreads();  // all waves are done with the K/V tiles before the region is reused
-  bf16_t* op = (bf16_t*)p.o + b * p.o_bs + h * HS;
-  store_tile_T<HS>(smem + wave * 32 * HS * 2, oacc, inv, op, p.o_ts, q0 + wave * 32, p.Tq, lane);
+  bf16_t* op = (bf16_t*)p.o + b * p.o_bs + h * DV;
+  store_tile_T<DV>(smem + wave * 32 * DV * 2, oacc, inv, op, p.o_ts, q0 + wave * 32, p.Tq, lane);
 #ifdef DPA_ATTN_TRACE
   if (tracing) {
     __syncthreads();
@@ -587,9 +596,10 @@ __device__ __forceinline__ void dma_dwords(unsigned lds_addr, unsigned voff, rsr
 }
 
 // dQ: one workgroup = 128 queries, sweeps the keys.
-template <int HS, bool DROP>
+template <int DK, int DV, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2;
+  constexpr int NK = DK / 16, NV = DV / 16, ND = DK / 32, KTILE = 64 * DK * 2, VTILE = 64 * DV * 2, STAGE = KTILE + VTILE;
+  constexpr int KCH = NK > 8 ? 8 : NK, DCH = ND > 4 ? 4 : ND;   // fragment batches (wide keys: several)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -601,38 +611,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int qt = nqt - 1 - rank;
   const int b = bh / p.nh, h = bh % p.nh, kvh = h / (p.nh / p.nkv);
   const int q0 = qt * 128, off = p.Tk - p.Tq;
-  const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * HS;
-  const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + h * HS;
-  const rsrc_t krs = make_rsrc((const bf16_t*)p.k + b * p.k_bs + kvh * HS);
-  const rsrc_t vrs = make_rsrc((const bf16_t*)p.v + b * p.v_bs + kvh * HS);
+  const bf16_t* qp = (const bf16_t*)p.q + b * p.q_bs + h * DK;
+  const bf16_t* dop = (const bf16_t*)p.dout + b * p.do_bs + h * DV;
+  const rsrc_t krs = make_rsrc((const bf16_t*)p.k + b * p.k_bs + kvh * DK);
+  const rsrc_t vrs = make_rsrc((const bf16_t*)p.v + b * p.v_bs + kvh * DV);
 
   int kv_end = q0 + 128 + off;
   if (kv_end > p.Tk) kv_end = p.Tk;
   const int ntiles = (kv_end + 63) / 64;
   const int wave_qmax = q0 + wave * 32 + 31;
 
-  TileDma<HS> kd, vd;
+  TileDma<DK> kd;
+  TileDma<DV> vd;
   kd.init(p.k_ts, wave, lane);
   vd.init(p.v_ts, wave, lane);
   kd.issue(krs, 0, p.Tk, lds0);
-  vd.issue(vrs, 0, p.Tk, lds0 + TILE);
+  vd.issue(vrs, 0, p.Tk, lds0 + KTILE);
 
   const float c = p.scale * kLog2e;
   const int qrow = q0 + wave * 32 + r;
-  bfrag qf[NK], dof[NK];
+  bfrag qf[NK], dof[NV];
   float nlse = -INFINITY, dlt = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < NK; ++ks) {
-    qf[ks] = zero_frag();
-    dof[ks] = zero_frag();
-  }
+  for (int ks = 0; ks < NK; ++ks) qf[ks] = zero_frag();
+#pragma unroll
+  for (int ks = 0; ks < NV; ++ks) dof[ks] = zero_frag();
   if (qrow < p.Tq) {
     // delta = rowsum(dO * O) from the dO fragments the kernel holds anyway (each lane half owns half
     // of the row).
-    const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * HS + (long long)qrow * p.o_ts;
+    const bf16_t* orow = (const bf16_t*)p.o + b * p.o_bs + h * DV + (long long)qrow * p.o_ts;
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      qf[ks] = scaled_frag(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8, c);
+    for (int ks = 0; ks < NK; ++ks) qf[ks] = scaled_frag(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8, c);
+#pragma unroll
+    for (int ks = 0; ks < NV; ++ks) {
       dof[ks] = *reinterpret_cast<const bfrag*>(dop + (long long)qrow * p.do_ts + ks * 16 + hh * 8);
       const u32x4 ov = *reinterpret_cast<const u32x4*>(orow + ks * 16 + hh * 8);
       const u32x4 dv = __builtin_bit_cast(u32x4, dof[ks]);
@@ -668,12 +679,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     wait_dma();
     __syncthreads();
     if (t + 1 < ntiles) {
-      const unsigned nb = lds0 + ((t + 1) & 1) * 2 * TILE;
+      const unsigned nb = lds0 + ((t + 1) & 1) * STAGE;
       kd.issue(krs, (t + 1) * 64, p.Tk, nb);
-      vd.issue(vrs, (t + 1) * 64, p.Tk, nb + TILE);
+      vd.issue(vrs, (t + 1) * 64, p.Tk, nb + KTILE);
     }
-    const char* kb = smem + (t & 1) * 2 * TILE;
-    const char* vb = kb + TILE;
+    const char* kb = smem + (t & 1) * STAGE;
+    const char* vb = kb + KTILE;
     const int kv0 = t * 64;
     const int wq0 = q0 + wave * 32 + off;
     // 32-key sub-tiles with a key visible to the wave. A rolled loop: with one `if` per unrolled
@@ -682,24 +693,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
       const int ks0 = kv0 + sub * 32;
-      const char* ksub = kb + sub * (32 * HS * 2);
-      const char* vsub = vb + sub * (32 * HS * 2);
-      bfrag kf[NK], vf[NK];
+      const char* ksub = kb + sub * (32 * DK * 2);
+      const char* vsub = vb + sub * (32 * DV * 2);
+      f32x16 s = negl, dp = negd;
+      if constexpr (NK <= 8) {
+        bfrag kf[NK], vf[NV];
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) kf[ks] = row_frag<HS>(ksub, r, ks, hh);
+        for (int ks = 0; ks < NK; ++ks) kf[ks] = row_frag<DK>(ksub, r, ks, hh);
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) vf[ks] = row_frag<HS>(vsub, r, ks, hh);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 s = mfma32(kf[0], qf[0], negl), dp = mfma32(vf[0], dof[0], negd);
+        for (int ks = 0; ks < NV; ++ks) vf[ks] = row_frag<DV>(vsub, r, ks, hh);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 1; ks < NK; ++ks) s = mfma32(kf[ks], qf[ks], s);
+        for (int ks = 0; ks < NK; ++ks) s = mfma32(kf[ks], qf[ks], s);
 #pragma unroll
-      for (int ks = 1; ks < NK; ++ks) dp = mfma32(vf[ks], dof[ks], dp);
-      bfrag kt[2][ND];
+        for (int ks = 0; ks < NV; ++ks) dp = mfma32(vf[ks], dof[ks], dp);
+      } else {
+        // wide keys: the fragments of a sub-tile would not fit in registers together
+#pragma unroll
+        for (int k0 = 0; k0 < NK; k0 += KCH) {
+          bfrag kf[KCH];
+#pragma unroll
+          for (int ks = 0; ks < KCH; ++ks) kf[ks] = row_frag<DK>(ksub, r, k0 + ks, hh);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < KCH; ++ks) s = mfma32(kf[ks], qf[k0 + ks], s);
+        }
+        bfrag vf[NV];
+#pragma unroll
+        for (int ks = 0; ks < NV; ++ks) vf[ks] = row_frag<DV>(vsub, r, ks, hh);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NV; ++ks) dp = mfma32(vf[ks], dof[ks], dp);
+      }
+      bfrag kt[2][DCH];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) kt[s2][dt] = tr_frag<HS>(ksub, 0, s2, dt, lane);
+        for (int dt = 0; dt < DCH; ++dt) kt[s2][dt] = tr_frag<DK>(ksub, 0, s2, dt, lane);
       __builtin_amdgcn_sched_barrier(0);
       // compare + select only where the diagonal or the end of the keys crosses the sub-tile
       if ((ks0 + 31 > wq0) || (ks0 + 32 > p.Tk)) {
@@ -715,17 +745,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         if (DROP) dpi = drop_keep(dkey, qrow, ks0 + acc_row(i, hh), dthr) ? (dpi + dlt) * rkeep - dlt : -dlt;
         s[i] = pv * dpi;  // dS^T
       }
+      const bfrag dsb0 = acc_frag(s, 0), dsb1 = acc_frag(s, 1);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bfrag dsb = acc_frag(s, s2);
+      for (int d0 = 0; d0 < ND; d0 += DCH) {
+        if (d0 > 0) {
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) dqacc[dt] = mfma32(kt[s2][dt], dsb, dqacc[dt]);
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < DCH; ++dt) kt[s2][dt] = tr_frag<DK>(ksub, 0, s2, d0 + dt, lane);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DCH; ++dt) {
+          dqacc[d0 + dt] = mfma32(kt[0][dt], dsb0, dqacc[d0 + dt]);
+          dqacc[d0 + dt] = mfma32(kt[1][dt], dsb1, dqacc[d0 + dt]);
+        }
       }
     }
   }
   __syncthreads();
-  bf16_t* dqp = (bf16_t*)p.dq + b * p.dq_bs + h * HS;
-  store_tile_T<HS>(smem + wave * 32 * HS * 2, dqacc, p.scale, dqp, p.dq_ts, q0 + wave * 32, p.Tq, lane, p.rope_cos,
+  bf16_t* dqp = (bf16_t*)p.dq + b * p.dq_bs + h * DK;
+  store_tile_T<DK>(smem + wave * 32 * DK * 2, dqacc, p.scale, dqp, p.dq_ts, q0 + wave * 32, p.Tq, lane, p.rope_cos,
                    p.rope_sin, p.rope_pos0 + (p.Tk - p.Tq));
 }
 
@@ -733,9 +773,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // Backward, dK/dV: one workgroup = 128 keys of one (batch, kv head); each wave keeps dK^T and
 // dV^T of its 32 keys in registers and sweeps the query heads of the group x the query tiles.
 // ------------------------------------------------------------------------------------------
-template <int HS, bool DROP>
+template <int DK, int DV, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
-  constexpr int NK = HS / 16, ND = HS / 32, TILE = 64 * HS * 2, BUF = 2 * TILE + 512;
+  constexpr int NK = DK / 16, NV = DV / 16, ND = DK / 32, NDV = DV / 32, QTILE = 64 * DK * 2, DOTILE = 64 * DV * 2;
+  constexpr int BUF = QTILE + DOTILE + 512;
+  constexpr int KCH = NK > 8 ? 8 : NK, DCH = ND > 4 ? 4 : ND;   // fragment batches (wide keys: several)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -747,20 +789,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int G = p.nh / p.nkv;
   const int k0 = kt * 128, off = p.Tk - p.Tq;
   const int kw0 = k0 + wave * 32;
-  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * HS;
-  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * HS;
+  const bf16_t* kp = (const bf16_t*)p.k + b * p.k_bs + kvh * DK;
+  const bf16_t* vp = (const bf16_t*)p.v + b * p.v_bs + kvh * DV;
   const float c = p.scale * kLog2e;
 
   const int key = kw0 + r;
-  bfrag kf[NK], vf[NK];
+  bfrag kf[NK], vf[NV];
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     kf[ks] = zero_frag();
+    if (key < p.Tk) kf[ks] = scaled_frag(kp + (long long)key * p.k_ts + ks * 16 + hh * 8, c);
+  }
+#pragma unroll
+  for (int ks = 0; ks < NV; ++ks) {
     vf[ks] = zero_frag();
-    if (key < p.Tk) {
-      kf[ks] = scaled_frag(kp + (long long)key * p.k_ts + ks * 16 + hh * 8, c);
-      vf[ks] = *reinterpret_cast<const bfrag*>(vp + (long long)key * p.v_ts + ks * 16 + hh * 8);
-    }
+    if (key < p.Tk) vf[ks] = *reinterpret_cast<const bfrag*>(vp + (long long)key * p.v_ts + ks * 16 + hh * 8);
   }
   int q_start = k0 - off;
   if (q_start < 0) q_start = 0;
@@ -768,18 +811,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const int nqt = (p.Tq - q_start + 63) / 64;
   const int niter = (nqt > 0 ? nqt : 0) * G;
 
-  f32x16 dkacc[ND], dvacc[ND];
+  f32x16 dkacc[ND], dvacc[NDV];
 #pragma unroll
   for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      dkacc[dt][i] = 0.f;
-      dvacc[dt][i] = 0.f;
-    }
+    for (int i = 0; i < 16; ++i) dkacc[dt][i] = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < NDV; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dvacc[dt][i] = 0.f;
   const unsigned dthr = DROP ? drop_threshold(p.p_drop) : 0u;
   const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
 
-  TileDma<HS> qd, dd;
+  TileDma<DK> qd;
+  TileDma<DV> dd;
   qd.init(p.q_ts, wave, lane);
   dd.init(p.do_ts, wave, lane);
   const int srows = stat_rows(p.Tq);
@@ -787,14 +832,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   // Q and dO tiles plus the 64 + 64 row constants of iteration `it` -> buffer `buf`
   auto issue = [&](int it, int buf) {
     const int hq = kvh * G + it / nqt, qt0 = q_start + (it % nqt) * 64;
-    const rsrc_t qrs = make_rsrc((const bf16_t*)p.q + b * p.q_bs + hq * HS);
-    const rsrc_t drs = make_rsrc((const bf16_t*)p.dout + b * p.do_bs + hq * HS);
+    const rsrc_t qrs = make_rsrc((const bf16_t*)p.q + b * p.q_bs + hq * DK);
+    const rsrc_t drs = make_rsrc((const bf16_t*)p.dout + b * p.do_bs + hq * DV);
     const unsigned base = lds0 + buf * BUF;
     qd.issue(qrs, qt0, p.Tq, base);
-    dd.issue(drs, qt0, p.Tq, base + TILE);
+    dd.issue(drs, qt0, p.Tq, base + QTILE);
     if (wave < 2) {   // wave 0: -lse * log2(e), wave 1: -delta
       const long long row = (long long)(wave == 0 ? p.B * p.nh : 0) * srows + ((long long)b * p.nh + hq) * srows + qt0;
-      dma_dwords(base + 2 * TILE + wave * 256, lane * 4, srs, __builtin_amdgcn_readfirstlane((unsigned)(row * 4)));
+      dma_dwords(base + QTILE + DOTILE + wave * 256, lane * 4, srs, __builtin_amdgcn_readfirstlane((unsigned)(row * 4)));
     }
   };
 
@@ -804,8 +849,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     __syncthreads();
     if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
     const char* qb = smem + (it & 1) * BUF;
-    const char* dob = qb + TILE;
-    const char* stb = qb + 2 * TILE;
+    const char* dob = qb + QTILE;
+    const char* stb = qb + QTILE + DOTILE;
     const int qt0 = q_start + (it % nqt) * 64;
     const unsigned dkey = DROP ? drop_key(p.seed, b * p.nh + kvh * G + it / nqt) : 0u;
     // 32-query sub-tiles with a (query, key) pair visible to the wave: [sub_lo, sub_hi). A rolled loop:
@@ -815,14 +860,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll 1
     for (int sub = sub_lo; sub < sub_hi; ++sub) {
       const int qs0 = qt0 + sub * 32;
-      const char* qsub = qb + sub * (32 * HS * 2);
-      const char* dosub = dob + sub * (32 * HS * 2);
+      const char* qsub = qb + sub * (32 * DK * 2);
+      const char* dosub = dob + sub * (32 * DV * 2);
       const char* stsub = stb + sub * 128;
-      bfrag qf[NK], dof[NK];
+      bfrag qf[KCH], dof[NV];
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) qf[ks] = row_frag<HS>(qsub, r, ks, hh);
+      for (int ks = 0; ks < KCH; ++ks) qf[ks] = row_frag<DK>(qsub, r, ks, hh);
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) dof[ks] = row_frag<HS>(dosub, r, ks, hh);
+      for (int ks = 0; ks < NV; ++ks) dof[ks] = row_frag<DV>(dosub, r, ks, hh);
       f32x16 s, dp;   // start as the row constants of the 16 queries a lane's accumulators belong to
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -839,17 +884,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       f32x16 nd;
       if (DROP) nd = dp;
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) s = mfma32(qf[ks], kf[ks], s);
+      for (int ks = 0; ks < KCH; ++ks) s = mfma32(qf[ks], kf[ks], s);
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) dp = mfma32(dof[ks], vf[ks], dp);
-      bfrag dot[2][ND], qt[2][ND];
+      for (int k0 = KCH; k0 < NK; k0 += KCH) {   // wide keys: the rest of the Q fragments, batch by batch
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+        for (int ks = 0; ks < KCH; ++ks) qf[ks] = row_frag<DK>(qsub, r, k0 + ks, hh);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-          dot[s2][dt] = tr_frag<HS>(dosub, 0, s2, dt, lane);
-          qt[s2][dt] = tr_frag<HS>(qsub, 0, s2, dt, lane);
-        }
+        for (int ks = 0; ks < KCH; ++ks) s = mfma32(qf[ks], kf[k0 + ks], s);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NV; ++ks) dp = mfma32(dof[ks], vf[ks], dp);
+      bfrag dot[2][NDV], qt[2][DCH];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < NDV; ++dt) dot[s2][dt] = tr_frag<DV>(dosub, 0, s2, dt, lane);
+#pragma unroll
+        for (int dt = 0; dt < DCH; ++dt) qt[s2][dt] = tr_frag<DK>(qsub, 0, s2, dt, lane);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // compare + select only on blocks the diagonal crosses
       if (kw0 + 31 > qs0 + off) {
@@ -869,53 +922,117 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         s[i] = pd;          // P (dropped and rescaled: the weights dV sees)
         dp[i] = pv * dpi;   // dS
       }
+      if constexpr (ND == NDV && ND <= 4) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bfrag pb = acc_frag(s, s2);
-        const bfrag dsb = acc_frag(dp, s2);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bfrag pb = acc_frag(s, s2);
+          const bfrag dsb = acc_frag(dp, s2);
 #pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-          dvacc[dt] = mfma32(dot[s2][dt], pb, dvacc[dt]);
-          dkacc[dt] = mfma32(qt[s2][dt], dsb, dkacc[dt]);
+          for (int dt = 0; dt < ND; ++dt) {
+            dvacc[dt] = mfma32(dot[s2][dt], pb, dvacc[dt]);
+            dkacc[dt] = mfma32(qt[s2][dt], dsb, dkacc[dt]);
+          }
+        }
+      } else {
+        const bfrag pb0 = acc_frag(s, 0), pb1 = acc_frag(s, 1), dsb0 = acc_frag(dp, 0), dsb1 = acc_frag(dp, 1);
+#pragma unroll
+        for (int dt = 0; dt < NDV; ++dt) {
+          dvacc[dt] = mfma32(dot[0][dt], pb0, dvacc[dt]);
+          dvacc[dt] = mfma32(dot[1][dt], pb1, dvacc[dt]);
+        }
+#pragma unroll
+        for (int d0 = 0; d0 < ND; d0 += DCH) {
+          if (d0 > 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int dt = 0; dt < DCH; ++dt) qt[s2][dt] = tr_frag<DK>(qsub, 0, s2, d0 + dt, lane);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int dt = 0; dt < DCH; ++dt) {
+            dkacc[d0 + dt] = mfma32(qt[0][dt], dsb0, dkacc[d0 + dt]);
+            dkacc[d0 + dt] = mfma32(qt[1][dt], dsb1, dkacc[d0 + dt]);
+          }
         }
       }
     }
   }
   __syncthreads();
-  bf16_t* dkp = (bf16_t*)p.dk + b * p.dk_bs + kvh * HS;
-  bf16_t* dvp = (bf16_t*)p.dv + b * p.dv_bs + kvh * HS;
-  char* wl = smem + wave * 32 * HS * 2;
-  store_tile_T<HS>(wl, dkacc, p.scale, dkp, p.dk_ts, kw0, p.Tk, lane, p.rope_cos, p.rope_sin, p.rope_pos0);
-  store_tile_T<HS>(wl, dvacc, 1.f, dvp, p.dv_ts, kw0, p.Tk, lane);
+  bf16_t* dkp = (bf16_t*)p.dk + b * p.dk_bs + kvh * DK;
+  bf16_t* dvp = (bf16_t*)p.dv + b * p.dv_bs + kvh * DV;
+  char* wl = smem + wave * 32 * DK * 2;
+  store_tile_T<DK>(wl, dkacc, p.scale, dkp, p.dk_ts, kw0, p.Tk, lane, p.rope_cos, p.rope_sin, p.rope_pos0);
+  store_tile_T<DV>(wl, dvacc, 1.f, dvp, p.dv_ts, kw0, p.Tk, lane);
 }
 
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
-template <int HS, bool DROP>
+template <int DK, int DV, bool DROP>
 static void fwd_launch(const AttnParams& p, hipStream_t st) {
   const int nqt = (p.Tq + 127) / 128;
-  const size_t lds = 4 * 64 * HS * 2;
-  hipLaunchKernelGGL((attn_fwd_kernel<HS, DROP>), dim3(nqt * p.B * p.nh), dim3(256), lds, st, p);
+  const size_t lds = 2 * (64 * DK * 2 + 64 * DV * 2);
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DK, DV, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, DROP>), dim3(nqt * p.B * p.nh), dim3(256), lds, st, p);
 }
 
-template <int HS, bool DROP>
+template <int DK, int DV, bool DROP>
 static void bwd_launch(const AttnParams& p, hipStream_t st) {
   // dQ first: it also produces delta, which the dK/dV kernel consumes.
   const int nqt = (p.Tq + 127) / 128;
-  const size_t lds_q = 4 * 64 * HS * 2;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HS, DROP>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
+  const size_t lds_q = 2 * (64 * DK * 2 + 64 * DV * 2);
   const int nkt = (p.Tk + 127) / 128;
-  const size_t lds_kv = 2 * (2 * 64 * HS * 2 + 512);
+  const size_t lds_kv = 2 * (64 * DK * 2 + 64 * DV * 2 + 512);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (lds_q > 65536)
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DK, DV, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_q);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DK, DV, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_kv);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS, DROP>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV, DROP>), dim3(nqt * p.B * p.nh), dim3(256), lds_q, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV, DROP>), dim3(nkt * p.B * p.nkv), dim3(256), lds_kv, st, p);
 }
 
+// Heads per XCD-local group. Measured on MI355X (benchmarks/attn_bench.py): groups of 4 heads gain
+// 3-5 % in the backward kernels and up to 9 % with grouped-query heads at T <= 2048; with more
+// than 16 tiles per head the longer tail of a group outweighs the L2 reuse. DPA_ATTN_GROUP overrides.
+static int tile_group(int tiles_per_head) {
+  static const int g = [] { const char* e = getenv("DPA_ATTN_GROUP"); return e ? atoi(e) : -1; }();
+  if (g >= 0) return g;
+  return tiles_per_head <= 16 ? 4 : 0;
+}
+
+#ifdef DPA_ATTN_WIDE
+// Key width != value width (multi-head latent attention with decoupled rotary keys: the key carries the rotary
+// columns behind the head's own, the value does not): (128, 64) and (256, 128). This translation unit is built
+// without the accumulators-in-VGPRs option of the square kernels: at key width 256 the dQ / dK accumulators alone
+// take 128 registers, and with them in AGPRs the operand fragments still fit the 256 architectural ones.
+bool attn_wide_ok(int dk, int dv) { return (dk == 128 && dv == 64) || (dk == 256 && dv == 128); }
+
+void attn_fwd_wide(const AttnParams& p0, hipStream_t st) {
+  AttnParams p = p0;
+  p.group = tile_group((p.Tq + 127) / 128);
+  const bool drop = p.p_drop > 0.f && p.seed != nullptr;
+  if (p.hs == 128) drop ? fwd_launch<128, 64, true>(p, st) : fwd_launch<128, 64, false>(p, st);
+  else drop ? fwd_launch<256, 128, true>(p, st) : fwd_launch<256, 128, false>(p, st);
+}
+
+void attn_bwd_wide(const AttnParams& p0, hipStream_t st) {
+  AttnParams p = p0;
+  p.group = tile_group((p.Tq + 127) / 128);
+  const bool drop = p.p_drop > 0.f && p.seed != nullptr;
+  if (p.hs == 128) drop ? bwd_launch<128, 64, true>(p, st) : bwd_launch<128, 64, false>(p, st);
+  else drop ? bwd_launch<256, 128, true>(p, st) : bwd_launch<256, 128, false>(p, st);
+}
+#else
 __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(unsigned char* __restrict__ keep, int nh, int Tq,
                                                                 int Tk, float p_drop,
                                                                 const long long* __restrict__ seed, long long total) {
@@ -939,31 +1056,25 @@ void attn_dropout_mask(unsigned char* keep, int B, int nh, int Tq, int Tk, float
                      total);
 }
 
-// Heads per XCD-local group. Measured on MI355X (benchmarks/attn_bench.py): groups of 4 heads gain
-// 3-5 % in the backward kernels and up to 9 % with grouped-query heads at T <= 2048; with more
-// than 16 tiles per head the longer tail of a group outweighs the L2 reuse. DPA_ATTN_GROUP overrides.
-static int tile_group(int tiles_per_head) {
-  static const int g = [] { const char* e = getenv("DPA_ATTN_GROUP"); return e ? atoi(e) : -1; }();
-  if (g >= 0) return g;
-  return tiles_per_head <= 16 ? 4 : 0;
-}
-
 void attn_fwd(const AttnParams& p0, hipStream_t st) {
   if (p0.B == 0 || p0.Tq == 0) return;
+  if (p0.vw != p0.hs) return attn_fwd_wide(p0, st);
   AttnParams p = p0;
   p.group = tile_group((p.Tq + 127) / 128);
   const bool drop = p.p_drop > 0.f && p.seed != nullptr;
-  if (p.hs == 64) drop ? fwd_launch<64, true>(p, st) : fwd_launch<64, false>(p, st);
-  else drop ? fwd_launch<128, true>(p, st) : fwd_launch<128, false>(p, st);
+  if (p.hs == 64) drop ? fwd_launch<64, 64, true>(p, st) : fwd_launch<64, 64, false>(p, st);
+  else drop ? fwd_launch<128, 128, true>(p, st) : fwd_launch<128, 128, false>(p, st);
 }
 
 void attn_bwd(const AttnParams& p0, hipStream_t st) {
   if (p0.B == 0 || p0.Tq == 0) return;
+  if (p0.vw != p0.hs) return attn_bwd_wide(p0, st);
   AttnParams p = p0;
   p.group = tile_group((p.Tq + 127) / 128);
   const bool drop = p.p_drop > 0.f && p.seed != nullptr;
-  if (p.hs == 64) drop ? bwd_launch<64, true>(p, st) : bwd_launch<64, false>(p, st);
-  else drop ? bwd_launch<128, true>(p, st) : bwd_launch<128, false>(p, st);
+  if (p.hs == 64) drop ? bwd_launch<64, 64, true>(p, st) : bwd_launch<64, 64, false>(p, st);
+  else drop ? bwd_launch<128, 128, true>(p, st) : bwd_launch<128, 128, false>(p, st);
 }
+#endif
 
 }  // namespace dpa

@@ -404,12 +404,15 @@ void check_heads(const Tensor& t, const char* name, int64_t hs) {
 }
 
 dpa::AttnParams attn_params(const Tensor& q, const Tensor& k, const Tensor& v, double scale) {
-  const int64_t hs = q.size(3);
-  TORCH_CHECK(hs == 64 || hs == 128, "attention: head size must be 64 or 128, got ", hs);
+  TORCH_CHECK(q.dim() == 4 && v.dim() == 4, "attention: [B, T, H, width] tensors");
+  const int64_t hs = q.size(3), dv = v.size(3);
+  TORCH_CHECK(((hs == 64 || hs == 128) && dv == hs) || dpa::attn_wide_ok((int)hs, (int)dv),
+              "attention: (key width, value width) must be (64, 64), (128, 128), (128, 64) or (256, 128), got (", hs, ", ", dv, ")");
   check_heads(q, "q", hs);
   check_heads(k, "k", hs);
-  check_heads(v, "v", hs);
-  TORCH_CHECK(k.size(0) == q.size(0) && v.sizes() == k.sizes(), "attention: k/v shape mismatch");
+  check_heads(v, "v", dv);
+  TORCH_CHECK(k.size(0) == q.size(0) && v.size(0) == k.size(0) && v.size(1) == k.size(1) && v.size(2) == k.size(2),
+              "attention: k/v shape mismatch");
   TORCH_CHECK(q.size(2) % k.size(2) == 0, "attention: n_head must be a multiple of n_kv_heads");
   TORCH_CHECK(k.size(1) >= q.size(1), "attention: Tk < Tq");
   dpa::AttnParams p{};
@@ -422,6 +425,7 @@ dpa::AttnParams attn_params(const Tensor& q, const Tensor& k, const Tensor& v, d
   p.Tk = (int)k.size(1);
   p.nkv = (int)k.size(2);
   p.hs = (int)hs;
+  p.vw = (int)dv;
   p.q_bs = q.stride(0);
   p.q_ts = (int)q.stride(1);
   p.k_bs = k.stride(0);
@@ -462,7 +466,8 @@ std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q, const Tensor& k, const Tens
                 "attention: kv_len must be a one-element int32 tensor on the GPU");
     p.kv_len = kv_len->data_ptr<int>();
   }
-  Tensor o = at::empty({q.size(0), q.size(1), q.size(2), q.size(3)}, q.options());
+  TORCH_CHECK(!kv_len.has_value() || v.size(3) == q.size(3), "attention: a cache fill level needs equal key and value widths");
+  Tensor o = at::empty({q.size(0), q.size(1), q.size(2), v.size(3)}, q.options());
   Tensor lse = at::empty({q.size(0), q.size(2), q.size(1)}, q.options().dtype(at::kFloat));
   p.o = o.data_ptr();
   p.o_bs = o.stride(0);
@@ -525,19 +530,20 @@ void attn_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor
   TORCH_CHECK(rope_cos.has_value() == rope_sin.has_value(), "attention backward: both rotary tables or none");
   if (rope_cos.has_value()) {
     TORCH_CHECK(rope_pos0 >= 0, "attention backward: rope_pos0 >= 0");
+    TORCH_CHECK(v.size(3) == q.size(3), "attention backward: rotary tables need equal key and value widths");
     check_rope_tables(*rope_cos, *rope_sin, q.size(3), rope_pos0 + k.size(1), "attention backward");
     p.rope_cos = rope_cos->data_ptr<float>();
     p.rope_sin = rope_sin->data_ptr<float>();
     p.rope_pos0 = (int)rope_pos0;
   }
-  const int64_t hs = q.size(3);
-  check_heads(dout, "dout", hs);
-  check_heads(o, "o", hs);
+  const int64_t hs = q.size(3), vw = v.size(3);
+  check_heads(dout, "dout", vw);
+  check_heads(o, "o", vw);
   check_heads(dq, "dq", hs);
   check_heads(dk, "dk", hs);
-  check_heads(dv, "dv", hs);
-  TORCH_CHECK(dout.sizes() == q.sizes() && o.sizes() == q.sizes() && dq.sizes() == q.sizes() &&
-                  dk.sizes() == k.sizes() && dv.sizes() == v.sizes(),
+  check_heads(dv, "dv", vw);
+  TORCH_CHECK(dout.sizes() == o.sizes() && o.size(0) == q.size(0) && o.size(1) == q.size(1) && o.size(2) == q.size(2) &&
+                  dq.sizes() == q.sizes() && dk.sizes() == k.sizes() && dv.sizes() == v.sizes(),
               "attention backward: shape mismatch");
   TORCH_CHECK(lse.is_cuda() && lse.scalar_type() == at::kFloat && lse.is_contiguous() &&
                   lse.numel() == q.size(0) * q.size(1) * q.size(2),

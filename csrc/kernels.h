@@ -55,7 +55,7 @@ void swiglu_fwd(const void* h, void* y, long long M, int U, bool is_bf16, hipStr
 void swiglu_bwd(const void* dy, const void* h, void* dh, long long M, int U, bool is_bf16, hipStream_t st);
 
 // ---- Attention (bf16, head size 64 or 128, causal, GQA-native) ---------------------------
-// Element (b, t, h, d) of a tensor X lives at X + b*X_bs + t*X_ts + h*HS + d, which lets the
+// Element (b, t, h, d) of a tensor X lives at X + b*X_bs + t*X_ts + h*W + d (W = the tensor's head width), which lets the
 // kernels read q/k/v straight out of a fused QKV projection and write dq/dk/dv straight into
 // the fused gradient buffer.
 struct AttnParams {
@@ -65,7 +65,8 @@ struct AttnParams {
   const void* dout;    // backward only
   float* delta;        // backward scratch, [2][B * nh][Tq rounded up to 128]: -rowsum(dO * O), -lse * log2(e)
   void *dq, *dk, *dv;
-  int B, nh, nkv, Tq, Tk, hs;
+  int B, nh, nkv, Tq, Tk, hs;   // hs: width of q and k
+  int vw;                       // width of v and o (== hs, or half of it: see attn_wide_ok)
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
   int q_ts, k_ts, v_ts, o_ts, do_ts, dq_ts, dk_ts, dv_ts;
   float scale;
@@ -85,6 +86,10 @@ struct AttnParams {
 };
 void attn_fwd(const AttnParams& p, hipStream_t st);
 void attn_bwd(const AttnParams& p, hipStream_t st);
+// key width != value width (csrc/attention_wide.hip): (128, 64) and (256, 128)
+bool attn_wide_ok(int dk, int dv);
+void attn_fwd_wide(const AttnParams& p, hipStream_t st);
+void attn_bwd_wide(const AttnParams& p, hipStream_t st);
 // keep[b, h, q, k] (1 byte each) of the dropout mask the attention kernels apply for this seed.
 void attn_dropout_mask(unsigned char* keep, int B, int nh, int Tq, int Tk, float p_drop, const long long* seed,
                        hipStream_t st);

@@ -218,9 +218,9 @@ def _mla_static_step(cache, q_eff, k_row, v_row, scale):
 
 
 def _mla_attention(q_eff, k_eff, v_lat, scale, dropout_p):
-    """Multi-query attention over latent keys/values: q_eff [B,T,nh,Dk], k_eff [B,Tk,1,Dk],
-    v_lat [B,Tk,1,Dv] -> [B,T,nh,Dv]. Key widths up to 128 run on the flash kernels (features are
-    zero-padded to 64 or 128 inside ``ops.causal_attention``), wider ones on the eager path."""
+    """Multi-query attention over latent keys/values (the absorbed form, used with KV caches): q_eff [B,T,nh,Dk],
+    k_eff [B,Tk,1,Dk], v_lat [B,Tk,1,Dv] -> [B,T,nh,Dv]. Widths the flash kernels are built for (zero-padded up
+    inside ``ops.causal_attention``) run on them, wider ones on the eager path."""
     return ops.causal_attention(q_eff, k_eff, v_lat, scale, dropout_p)
 
 
@@ -254,6 +254,20 @@ class NaiveMHLA(nn.Module):
         B, T, C = x.shape
         nh, n_kvl, hs = self.config.n_head, self.config.kv_latent_dim, self.head_size
         p_drop = self.config.dropout if self.training else 0.0
+        new_c_kv = ops.linear(x, self.W_dkv.weight)
+        q = ops.linear(ops.linear(x, self.W_dq.weight), self.W_uq.weight).view(B, T, nh, hs)
+        if kv_cache is None and (self.training or VAL_RUN):
+            # Per-head form of the same function (no latent-wide scores): the absorbed key matrix is applied to the
+            # latent rows instead of the queries, K = c_kv (W_dq^T W_uq^T W_uk)^T, and the value / output products
+            # to the latent rows instead of the context, V = (c_kv W_uv^T) W_o^T. Scores and context are then
+            # ordinary hs-wide heads, which the flash kernels take; FLOPs per (query, key) pair drop from
+            # 2 n_kvl to 2 hs.
+            w_k = self.W_dq.weight.t() @ self.W_uq.weight.t() @ self.W_uk.weight          # (C, n_kvl): k_abs, not re-viewed
+            k_heads = ops.linear(new_c_kv, w_k.to(q.dtype)).view(B, T, nh, hs)
+            v_heads = ops.linear(ops.linear(new_c_kv, self.W_uv.weight), self.W_o.weight).view(B, T, nh, hs)
+            y = ops.causal_attention(q, k_heads, v_heads, 1.0 / math.sqrt(hs), p_drop).reshape(B, T, C)
+            y = _drop(y, self.config.dropout, self.training)
+            return y, new_c_kv
         if self.training or VAL_RUN:
             k_abs, v_abs = self._absorbed()
         else:
@@ -262,8 +276,6 @@ class NaiveMHLA(nn.Module):
                     k_abs, v_abs = self._absorbed()
                     self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
             k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
-        new_c_kv = ops.linear(x, self.W_dkv.weight)
-        q = ops.linear(ops.linear(x, self.W_dq.weight), self.W_uq.weight).view(B, T, nh, hs)
         q_eff = torch.einsum("bthd,hdl->bthl", q, k_abs.to(q.dtype))          # (B, T, nh, n_kvl)
         if isinstance(kv_cache, _StaticLayer):
             ctx = _mla_static_step(kv_cache, q_eff, new_c_kv, new_c_kv, 1.0 / math.sqrt(hs))
@@ -313,6 +325,23 @@ class FullMHLA(nn.Module):
         p_drop = self.config.dropout if self.training else 0.0
         cos_t, sin_t, pos0 = rope
         c_q = ops.linear(x, self.W_dq.weight)                                   # (B, T, nlq)
+        new_c_kv = ops.linear(x, self.W_dkv.weight)
+        k_r = ops.apply_rope(ops.linear(x, self.W_kr.weight).view(B, T, 1, dhr), cos_t, sin_t, pos0)
+        q_r = ops.apply_rope(ops.linear(c_q, self.W_qr.weight).view(B, T, nh, dhr), cos_t, sin_t, pos0)
+        if kv_cache is None and (self.training or VAL_RUN):
+            # Per-head form of the same function: q_nope . c_kv = (c_q A_h) . (W_uk_h c_kv) with A = W_uq.weight
+            # re-viewed as (nlq, C), so the scores are [Q_h | q_r] . [K_h | k_r], hs + dhr wide instead of
+            # nlkv + dhr, and V = (c_kv W_uv^T) W_o^T carries the output product, hs wide instead of nlkv.
+            # (key, value) widths (256, 128) for the 1024 / 8 heads / rope 128 configuration: flash kernels.
+            nlq = self.config.q_latent_dim
+            q_heads = ops.linear(c_q, self.W_uq.weight.view(nlq, C).t().contiguous()).view(B, T, nh, hs)
+            k_heads = ops.linear(new_c_kv, self.W_uk.weight).view(B, T, nh, hs)
+            v_heads = ops.linear(ops.linear(new_c_kv, self.W_uv.weight), self.W_o.weight).view(B, T, nh, hs)
+            q_full = torch.cat([q_heads, q_r], dim=-1)
+            k_full = torch.cat([k_heads, k_r.expand(B, T, nh, dhr)], dim=-1)
+            y = ops.causal_attention(q_full, k_full, v_heads, 1.0 / math.sqrt(hs + dhr), p_drop).reshape(B, T, C)
+            y = _drop(y, self.config.dropout, self.training)
+            return y, {"c_kv": new_c_kv, "k_r": k_r.transpose(1, 2)}
         if self.training or VAL_RUN:
             k_abs, v_abs = self._absorbed()
         else:
@@ -321,9 +350,6 @@ class FullMHLA(nn.Module):
                     k_abs, v_abs = self._absorbed()
                     self._k_absorbed_inference, self._v_absorbed_inference = k_abs.clone(), v_abs.clone()
             k_abs, v_abs = self._k_absorbed_inference, self._v_absorbed_inference
-        new_c_kv = ops.linear(x, self.W_dkv.weight)
-        k_r = ops.apply_rope(ops.linear(x, self.W_kr.weight).view(B, T, 1, dhr), cos_t, sin_t, pos0)
-        q_r = ops.apply_rope(ops.linear(c_q, self.W_qr.weight).view(B, T, nh, dhr), cos_t, sin_t, pos0)
         q_nope = torch.einsum("btq,hql->bthl", c_q, k_abs.to(c_q.dtype))       # (B, T, nh, nlkv)
         q_eff = torch.cat([q_nope, q_r], dim=-1)                               # (B, T, nh, nlkv + dhr)
         if isinstance(kv_cache, _StaticLayer):

@@ -5,7 +5,8 @@
 ``o [B, Tq, nh, hs]``. Query ``i`` attends to keys ``<= i + Tk - Tq``; with ``Tq == Tk`` this is
 the usual causal mask and with a KV cache (``Tq < Tk``) the new tokens see the whole cache.
 
-GPU path: the hand-written flash kernels (bf16, hs in {64, 128}; other widths up to 128 zero-padded).
+GPU path: the hand-written flash kernels (bf16; key / value widths (64, 64), (128, 128), (128, 64) and
+(256, 128) — the last two for latent attention with decoupled rotary keys; other widths zero-padded up).
 Attention dropout runs inside them: the keep mask is a stateless hash of (seed, head, query, key)
 that the forward and both backward kernels regenerate, the seed is one device integer drawn from
 torch's GPU generator (so ``manual_seed``, activation recomputation and hipGraph replay treat it like
@@ -27,17 +28,20 @@ import torch.nn.functional as F
 from .._ext import ops, use_hip
 
 
+_WIDTHS = ((64, 64), (128, 128), (128, 64), (256, 128))   # (key width, value width) the kernels are built for
+
+
 def _hip_ok(q, k, v) -> bool:
     return (use_hip(q, k, v) and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16
-            and v.dtype == torch.bfloat16 and q.shape[-1] in (64, 128) and k.shape[-1] == q.shape[-1]
-            and v.shape[-1] == q.shape[-1] and q.shape[1] >= 1)
+            and v.dtype == torch.bfloat16 and (q.shape[-1], v.shape[-1]) in _WIDTHS and k.shape[-1] == q.shape[-1]
+            and q.shape[1] >= 1)
 
 
 def _paddable(q, k, v) -> bool:
     """bf16 GPU tensors whose head sizes are not native to the kernels but fit after zero padding."""
     return (use_hip(q, k, v) and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16
-            and q.shape[-1] == k.shape[-1] and max(q.shape[-1], v.shape[-1]) <= 128 and q.shape[1] >= 1
-            and k.shape[2] == v.shape[2] and q.shape[2] % k.shape[2] == 0)
+            and q.shape[-1] == k.shape[-1] and any(a >= q.shape[-1] and b >= v.shape[-1] for a, b in _WIDTHS)
+            and q.shape[1] >= 1 and k.shape[2] == v.shape[2] and q.shape[2] % k.shape[2] == 0)
 
 
 def _packed(t: torch.Tensor) -> torch.Tensor:
@@ -78,7 +82,7 @@ class _FlashAttnFn(torch.autograd.Function):
         B, Tq, nh, hs = q.shape
         Tk, nkv = k.shape[1], k.shape[2]
         do = _packed(do)
-        if Tq == Tk:
+        if Tq == Tk and v.shape[-1] == hs:
             # One fused [B, T, (nh + 2 nkv) hs] gradient buffer: the QKV projection's backward
             # GEMMs consume it without a concatenation.
             dqkv = torch.empty(B, Tq, (nh + 2 * nkv) * hs, dtype=q.dtype, device=q.device)
@@ -229,12 +233,13 @@ def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
     if _hip_ok(q, k, v):
         return _FlashAttnFn.apply(q, k, v, float(scale), dropout_p, seed)
     if _paddable(q, k, v):
-        # Other head sizes up to 128 run on the flash kernels too: zero features change neither the
-        # scores (the scale is explicit) nor the kept output columns, and no T x T matrix is formed.
+        # Other widths run on the flash kernels too, zero-padded to the next pair they are built for: zero
+        # features change neither the scores (the scale is explicit) nor the kept output columns, and no
+        # T x T matrix is formed.
         hs, dv = q.shape[-1], v.shape[-1]
-        tgt = 64 if max(hs, dv) <= 64 else 128
-        qp, kp = F.pad(q, (0, tgt - hs)), F.pad(k, (0, tgt - hs))
-        vp = F.pad(v, (0, tgt - dv))
+        tk, tv = next((a, b) for (a, b) in sorted(_WIDTHS, key=lambda w: w[0] * 3 + w[1]) if a >= hs and b >= dv)
+        qp, kp = F.pad(q, (0, tk - hs)), F.pad(k, (0, tk - hs))
+        vp = F.pad(v, (0, tv - dv))
         return _FlashAttnFn.apply(qp, kp, vp, float(scale), dropout_p, seed)[..., :dv]
     return causal_attention_eager(q, k, v, float(scale), dropout_p)
 

@@ -298,6 +298,139 @@ def test_flash_attention_fwd_bwd(B, Tq, Tk, nh, nkv, hs):
     assert rel_err(v.grad, vr.grad) < 2e-2
 
 
+@pytest.mark.parametrize("B,Tq,Tk,nh,nkv,dk,dv,p_drop", [
+    (2, 384, 384, 4, 4, 256, 128, 0.0),    # latent attention with 128 rotary columns behind 128-wide heads
+    (1, 300, 300, 8, 8, 256, 128, 0.0),    # ragged T
+    (2, 256, 256, 4, 2, 256, 128, 0.0),    # grouped keys
+    (2, 320, 320, 4, 4, 128, 64, 0.0),
+    (1, 64, 200, 4, 4, 256, 128, 0.0),     # queries at the end of a longer key range
+    (2, 200, 200, 4, 4, 192, 100, 0.0),    # zero-padded up to (256, 128)
+])
+def test_flash_attention_key_wider_than_value(B, Tq, Tk, nh, nkv, dk, dv, p_drop):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(18)
+    q = torch.randn(B, Tq, nh, dk, device=DEV).to(torch.bfloat16).requires_grad_()
+    k = torch.randn(B, Tk, nkv, dk, device=DEV).to(torch.bfloat16).requires_grad_()
+    v = torch.randn(B, Tk, nkv, dv, device=DEV).to(torch.bfloat16).requires_grad_()
+    scale = 1.0 / math.sqrt(dk)
+    o = ops.causal_attention(q, k, v, scale, p_drop)
+    assert o.shape == (B, Tq, nh, dv)
+    g = torch.randn_like(o)
+    o.backward(g)
+    qr, kr, vr = [t.detach().float().requires_grad_() for t in (q, k, v)]
+    orf = _attn_ref(qr, kr, vr, scale)
+    orf.backward(g.float())
+    assert rel_err(o, orf) < 1e-2
+    assert rel_err(q.grad, qr.grad) < 2e-2
+    assert rel_err(k.grad, kr.grad) < 2e-2
+    assert rel_err(v.grad, vr.grad) < 2e-2
+
+
+def test_flash_attention_key_wider_than_value_dropout_is_consistent():
+    """Dropout on the (256, 128) kernels: forward and both backward kernels regenerate the same mask (the result
+    equals the explicit-mask reference built from the mask the kernels report for the seed)."""
+    from distributed_pytorch_amd import ops
+    from distributed_pytorch_amd.ops.attention import dropout_keep_mask
+    torch.manual_seed(19)
+    B, T, nh, dk, dv, p = 2, 256, 4, 256, 128, 0.2
+    q = torch.randn(B, T, nh, dk, device=DEV).to(torch.bfloat16).requires_grad_()
+    k = torch.randn(B, T, nh, dk, device=DEV).to(torch.bfloat16).requires_grad_()
+    v = torch.randn(B, T, nh, dv, device=DEV).to(torch.bfloat16).requires_grad_()
+    seed = torch.tensor([12345], dtype=torch.int64, device=DEV)
+    scale = 1.0 / math.sqrt(dk)
+    o = ops.causal_attention(q, k, v, scale, p, seed)
+    g = torch.randn_like(o)
+    o.backward(g)
+    keep = dropout_keep_mask(B, nh, T, T, p, seed)
+    qr, kr, vr = [t.detach().float().requires_grad_() for t in (q, k, v)]
+    sc = (qr.transpose(1, 2) @ kr.transpose(1, 2).transpose(-1, -2)) * scale
+    sc = sc.masked_fill(~torch.ones(T, T, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+    pr = torch.softmax(sc, dim=-1) * keep / (1 - p)
+    orf = (pr @ vr.transpose(1, 2)).transpose(1, 2)
+    orf.backward(g.float())
+    assert rel_err(o, orf) < 1e-2
+    assert rel_err(q.grad, qr.grad) < 2e-2 and rel_err(k.grad, kr.grad) < 2e-2 and rel_err(v.grad, vr.grad) < 2e-2
+
+
+def _attn_check_chunked(q, k, v, g, o, scale, heads_per_chunk=8):
+    """fp32 reference of output and gradients, computed per batch element and group of heads (the score matrices
+    of the large shapes do not fit at once): the worst relative errors."""
+    B, T, nh, hs = q.shape
+    nkv = k.shape[2]
+    G = nh // nkv
+    worst = [0.0, 0.0, 0.0, 0.0]
+    dk_ref = torch.zeros_like(k, dtype=torch.float32)
+    dv_ref = torch.zeros_like(v, dtype=torch.float32)
+    dq_ref = torch.zeros_like(q, dtype=torch.float32)
+    o_ref = torch.zeros_like(o, dtype=torch.float32)
+    for b in range(B):
+        for h0 in range(0, nh, heads_per_chunk):
+            hsl = slice(h0, h0 + heads_per_chunk)
+            ksl = slice(h0 // G, (h0 + heads_per_chunk + G - 1) // G)
+            qr = q[b:b + 1, :, hsl].detach().float().requires_grad_()
+            kr = k[b:b + 1, :, ksl].detach().float().requires_grad_()
+            vr = v[b:b + 1, :, ksl].detach().float().requires_grad_()
+            orf = _attn_ref(qr, kr, vr, scale)
+            orf.backward(g[b:b + 1, :, hsl].float())
+            o_ref[b:b + 1, :, hsl] = orf.detach()
+            dq_ref[b:b + 1, :, hsl] = qr.grad
+            dk_ref[b:b + 1, :, ksl] += kr.grad
+            dv_ref[b:b + 1, :, ksl] += vr.grad
+    return rel_err(o, o_ref), rel_err(q.grad, dq_ref), rel_err(k.grad, dk_ref), rel_err(v.grad, dv_ref)
+
+
+@pytest.mark.parametrize("B,T,nh,nkv,hs", [
+    (64, 1024, 12, 12, 64),     # the headline's attention at micro-batch 64: 768 (batch, head) pairs, XCD-grouped order
+    (16, 2048, 32, 8, 128),     # 1.3B-class heads with grouped keys at T = 2048
+])
+def test_flash_attention_at_benchmarked_shapes(B, T, nh, nkv, hs):
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(20)
+    q = torch.randn(B, T, nh, hs, device=DEV).to(torch.bfloat16).requires_grad_()
+    k = torch.randn(B, T, nkv, hs, device=DEV).to(torch.bfloat16).requires_grad_()
+    v = torch.randn(B, T, nkv, hs, device=DEV).to(torch.bfloat16).requires_grad_()
+    scale = 1.0 / math.sqrt(hs)
+    o = ops.causal_attention(q, k, v, scale)
+    g = torch.randn_like(o)
+    o.backward(g)
+    G = nh // nkv
+    eo, eq, ek, ev = _attn_check_chunked(q, k, v, g, o, scale, heads_per_chunk=max(G, 4))
+    assert eo < 1e-2 and eq < 2e-2 and ek < 2e-2 and ev < 2e-2, (eo, eq, ek, ev)
+
+
+@pytest.mark.parametrize("hs", [64, 128])
+def test_flash_attention_underflowing_and_mixed_first_tiles(hs):
+    """The forward keeps a fixed reference point until a tile's probabilities leave [1e-9, 1e9]. Rows whose every score
+    in the first key tile is far below zero (k = -4 q: the first tile underflows and has to be redone with a row
+    maximum), rows with a huge early score (overflow), and ordinary rows, side by side in the same 32-row blocks."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(21)
+    B, T, nh = 2, 256, 4
+    q = torch.randn(B, T, nh, hs, device=DEV)
+    k = torch.randn(B, T, nh, hs, device=DEV)
+    v = torch.randn(B, T, nh, hs, device=DEV)
+    # head 0: every key opposes every query direction -> all scores strongly negative (underflow everywhere)
+    base = torch.randn(hs, device=DEV)
+    base = base / base.norm() * math.sqrt(hs)          # scores of head 0: about -4 sqrt(hs) (e^-32 and below)
+    q[:, :, 0] = base + 0.05 * torch.randn(B, T, hs, device=DEV)
+    k[:, :, 0] = -4.0 * q[:, :, 0]
+    # head 1: odd rows underflow against the first 64 keys, even rows see one very large score among them
+    k[:, :64, 1] = -4.0 * q[:, 65:66, 1]
+    q[:, 1::2, 1] = q[:, 65:66, 1]
+    q[:, 0::2, 1] = -1.5 * q[:, 65:66, 1]              # +6 sqrt(hs): e^48 and above
+    q, k, v = [t.to(torch.bfloat16).requires_grad_() for t in (q, k, v)]
+    scale = 1.0 / math.sqrt(hs)
+    o = ops.causal_attention(q, k, v, scale)
+    g = torch.randn_like(o)
+    o.backward(g)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(q.grad.float()).all()
+    qr, kr, vr = [t.detach().float().requires_grad_() for t in (q, k, v)]
+    orf = _attn_ref(qr, kr, vr, scale)
+    orf.backward(g.float())
+    assert rel_err(o, orf) < 1e-2
+    assert rel_err(q.grad, qr.grad) < 3e-2 and rel_err(k.grad, kr.grad) < 3e-2 and rel_err(v.grad, vr.grad) < 2e-2
+
+
 def test_flash_attention_fused_qkv_and_spike():
     """Fused-QKV entry point + a row whose max jumps late (exercises the online-softmax rescale)."""
     from distributed_pytorch_amd import ops

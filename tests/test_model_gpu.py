@@ -19,6 +19,11 @@ VARIANTS = {
     "mla_rope_flash": dict(attn="mla", pos_emb="rope", q_latent_dim=64, kv_latent_dim=96, rope_head_dim=32),
     "mla_naive_flash": dict(attn="mla", pos_emb="learn", q_latent_dim=64, kv_latent_dim=64),
     "mla_rope_small_latent": dict(attn="mla", pos_emb="rope", q_latent_dim=32, kv_latent_dim=32, rope_head_dim=16),
+    # the reference's own launch configuration of latent attention (single-gpu/train.sh:34-36): 128-wide heads with
+    # 128 rotary columns -> (key, value) widths (256, 128)
+    "mla_rope_wide": dict(attn="mla", pos_emb="rope", n_embd=1024, n_head=8, up_dim=2048, q_latent_dim=256,
+                          kv_latent_dim=256, rope_head_dim=128),
+    "mla_rope_128_64": dict(attn="mla", pos_emb="rope", q_latent_dim=64, kv_latent_dim=64, rope_head_dim=64),
     "mha_hs32": dict(attn="mha", n_head=8, pos_emb="learn", non_linearity="gelu"),
     "moe": dict(attn="mha", pos_emb="learn", non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2),
     "recompute": dict(attn="mha", pos_emb="learn", non_linearity="gelu", act_recomp=True),
