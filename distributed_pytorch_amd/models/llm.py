@@ -484,23 +484,24 @@ class MoE(nn.Module):
 
     def routed_experts_local(self, x_flat, topk_indices, topk_gates):
         """Routed experts on this rank. GPU path: grouped expert GEMMs over the padded expert-sorted
-        layout (no host sync). Fallback (CPU, dropout inside the experts, activations without a
+        layout (no host sync). Fallback (CPU, activations without a
         grouped kernel): sort the (token, slot) pairs by expert once, run every expert on its
         contiguous slice, scale by the gate and scatter-add back, with one host read of the
         per-expert counts instead of the reference's per-expert ``nonzero``."""
         N, k = topk_indices.shape
         routed = self.experts[self.n_shared:]
-        if not (self.training and self.config.dropout > 0):
-            fcs = [e.expert.c_fc.weight for e in routed]
-            projs = [e.expert.c_proj.weight for e in routed]
-            act = routed[0].expert.non_linearity
-            if ops.grouped_supported(x_flat, fcs, projs, act):
-                # padded expert-sorted layout + grouped MFMA GEMMs: no host sync, no expert loop
-                layout = None
-                if getattr(self, "_layout", None) is not None and self._layout[0] is topk_indices:
-                    layout = self._layout[1]
-                self._layout = None
-                return ops.grouped_experts(x_flat, topk_indices, topk_gates, fcs, projs, act, layout)
+        fcs = [e.expert.c_fc.weight for e in routed]
+        projs = [e.expert.c_proj.weight for e in routed]
+        act = routed[0].expert.non_linearity
+        if ops.grouped_supported(x_flat, fcs, projs, act):
+            # padded expert-sorted layout + grouped MFMA GEMMs: no host sync, no expert loop (dropout on the
+            # experts' outputs included: its mask is drawn on the device in the same layout)
+            layout = None
+            if getattr(self, "_layout", None) is not None and self._layout[0] is topk_indices:
+                layout = self._layout[1]
+            self._layout = None
+            p_drop = self.config.dropout if self.training else 0.0
+            return ops.grouped_experts(x_flat, topk_indices, topk_gates, fcs, projs, act, layout, p_drop=p_drop)
         flat_e = topk_indices.reshape(-1)
         order = torch.argsort(flat_e, stable=True)
         tok = torch.div(order, k, rounding_mode="floor")

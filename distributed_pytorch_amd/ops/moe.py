@@ -269,9 +269,23 @@ def _emit_wgrads(ws32, params, needs):
     return out
 
 
+def _keep_rows(y, p_drop: float, keep_pairs, row_of_pair):
+    """Scaled keep mask (0 or 1 / (1 - p), y's dtype) for dropout on the experts' outputs in the padded expert-sorted
+    layout: drawn from torch's GPU generator (so manual_seed, recomputation and hipGraph replay treat it like any
+    other random op), or placed from a given ``keep_pairs [N, k, C]`` (tests). None without dropout."""
+    if p_drop <= 0.0:
+        return None
+    if keep_pairs is None:
+        keep = torch.rand_like(y, dtype=torch.float32) >= p_drop
+    else:
+        keep = torch.zeros(y.shape, dtype=torch.bool, device=y.device)
+        keep[row_of_pair.reshape(-1).long()] = keep_pairs.reshape(-1, y.shape[1]).to(torch.bool)
+    return keep.to(y.dtype) * (1.0 / (1.0 - p_drop))
+
+
 class _GroupedExpertsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_flat, gates, topk_indices, act, layout, *weights):
+    def forward(ctx, x_flat, gates, topk_indices, act, layout, p_drop, keep_pairs, *weights):
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         k = topk_indices.shape[1]
@@ -281,9 +295,12 @@ class _GroupedExpertsFn(torch.autograd.Function):
         h = ops().grouped_gemm(xs, fc_ptrs, fc[0].shape[0], fc[0].shape[1], False, block_group)
         a = _act_fwd(h, act)
         y = ops().grouped_gemm(a, proj_ptrs, proj[0].shape[0], proj[0].shape[1], False, block_group)
+        keep = _keep_rows(y, p_drop, keep_pairs, row_of_pair)
+        if keep is not None:
+            y = y * keep            # dropout sits on every expert's output, before the gate (reference: Expert -> MLP)
         gates_c = gates.contiguous()
         out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
-        ctx.save_for_backward(xs, h, y, gates_c, row_of_pair, block_group, seg_start, seg_rows)
+        ctx.save_for_backward(xs, h, y, gates_c, row_of_pair, block_group, seg_start, seg_rows, keep)
         ctx.params = weights
         ctx.act = act
         ctx.k = k
@@ -291,14 +308,16 @@ class _GroupedExpertsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        xs, h, y, gates, row_of_pair, block_group, seg_start, seg_rows = ctx.saved_tensors
+        xs, h, y, gates, row_of_pair, block_group, seg_start, seg_rows, keep = ctx.saved_tensors
         weights = ctx.params
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         # Addresses are looked up again: a sharding engine may have re-materialised the weights.
         fc_ptrs, proj_ptrs = _ptr_table(fc), _ptr_table(proj)
-        needs = ctx.needs_input_grad[5:]
+        needs = ctx.needs_input_grad[7:]
         dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        if keep is not None:
+            dy = dy * keep
         a = _act_fwd(h, ctx.act)
         g_proj = [None] * E
         if any(needs[E:]):
@@ -315,7 +334,7 @@ class _GroupedExpertsFn(torch.autograd.Function):
             dxs = ops().grouped_gemm(dh, fc_ptrs, fc[0].shape[0], fc[0].shape[1], True, block_group)
             dx = ops().moe_gather_combine(dxs, row_of_pair, None, ctx.k)
         dg = dgate.to(gates.dtype) if ctx.needs_input_grad[1] else None
-        return (dx, dg, None, None, None, *g_fc, *g_proj)
+        return (dx, dg, None, None, None, None, None, *g_fc, *g_proj)
 
 
 _EPI_GELU, _EPI_MUL, _EPI_SWIGLU, _EPI_DSWIGLU = 1, 2, 4, 5   # epilogues of the NT GEMM (csrc/kernels.h)
@@ -344,7 +363,7 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
     """The routed experts of a layer as four grouped NT GEMMs and two grouped weight gradients."""
 
     @staticmethod
-    def forward(ctx, x_flat, gates, topk_indices, layout, act, *weights):
+    def forward(ctx, x_flat, gates, topk_indices, layout, act, p_drop, keep_pairs, *weights):
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         k = topk_indices.shape[1]
@@ -357,9 +376,12 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
         a, side = ops().gemm_nt_grouped(xs, _ptr_table(fc), U, C, _EPI_SWIGLU if act == "swiglu" else _EPI_GELU, None,
                                         block_group)
         y = ops().gemm_nt_grouped(a, _ptr_table(proj), C, U, 0, None, block_group)[0]
+        keep = _keep_rows(y, p_drop, keep_pairs, row_of_pair)
+        if keep is not None:
+            y = y * keep            # dropout sits on every expert's output, before the gate (reference: Expert -> MLP)
         gates_c = gates.contiguous()
         out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
-        ctx.save_for_backward(xs, a, side, y, gates_c, row_of_pair, block_group, seg_start, seg_rows)
+        ctx.save_for_backward(xs, a, side, y, gates_c, row_of_pair, block_group, seg_start, seg_rows, keep)
         ctx.params = weights
         ctx.k = k
         ctx.act = act
@@ -368,14 +390,16 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         from .linear import transposed_weight
-        xs, a, side, y, gates, row_of_pair, block_group, seg_start, seg_rows = ctx.saved_tensors
+        xs, a, side, y, gates, row_of_pair, block_group, seg_start, seg_rows, keep = ctx.saved_tensors
         weights = ctx.params
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         W, C = fc[0].shape                 # W = U, or 2U with SwiGLU experts
         U = proj[0].shape[1]
-        needs = ctx.needs_input_grad[5:]
+        needs = ctx.needs_input_grad[7:]
         dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        if keep is not None:
+            dy = dy * keep
         g_proj = [None] * E
         if any(needs[E:]):
             g_proj = _wgrads(dy, a, seg_start, seg_rows, proj, needs[E:])
@@ -393,7 +417,7 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
             dxs = ops().gemm_nt_grouped(dh, _ptr_table(fc_t), C, W, 0, None, block_group)[0]
             dx = ops().moe_gather_combine(dxs, row_of_pair, None, ctx.k)
         dg = dgate.to(gates.dtype) if ctx.needs_input_grad[1] else None
-        return (dx, dg, None, None, None, *g_fc, *g_proj)
+        return (dx, dg, None, None, None, None, None, *g_fc, *g_proj)
 
 
 def grouped_layout_block(x_flat, fc_weights, proj_weights, act: str, k: int = 8) -> int:
@@ -417,22 +441,31 @@ def grouped_supported(x_flat, fc_weights, proj_weights, act: str) -> bool:
     return ok
 
 
-def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str, layout=None) -> torch.Tensor:
-    """sum_s gate[t, s] * expert_{idx[t, s]}(x[t]) for bias-free two-layer experts
+def grouped_experts(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str, layout=None,
+                    p_drop: float = 0.0, keep_pairs=None) -> torch.Tensor:
+    """sum_s gate[t, s] * drop(expert_{idx[t, s]}(x[t])) for bias-free two-layer experts
     (``act`` = "swiglu" or an elementwise activation of the reference's table) on the grouped HIP kernels. ``layout`` = a ``plan()`` result for
-    ``topk_indices`` if the caller already has one."""
+    ``topk_indices`` if the caller already has one. ``p_drop`` > 0: dropout on every expert's output (mask drawn on
+    the device: no host work, so the layer stays capturable); ``keep_pairs [N, k, C]`` pins the mask (tests)."""
     assert len(fc_weights) == len(proj_weights)
+    p_drop = float(p_drop)
     if _nt_grouped_ok(x_flat, fc_weights, proj_weights, act, topk_indices.shape[1]) and \
             (layout is None or layout[1].numel() * NT_BLOCK == layout[4]):
-        return _GroupedExpertsNtFn.apply(x_flat, topk_gates, topk_indices, layout, act, *fc_weights, *proj_weights)
+        return _GroupedExpertsNtFn.apply(x_flat, topk_gates, topk_indices, layout, act, p_drop, keep_pairs,
+                                         *fc_weights, *proj_weights)
     if layout is not None and layout[1].numel() * BLOCK != layout[4]:
         layout = None      # made for the other kernels' block size
-    return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, layout, *fc_weights, *proj_weights)
+    return _GroupedExpertsFn.apply(x_flat, topk_gates, topk_indices, act, layout, p_drop, keep_pairs,
+                                   *fc_weights, *proj_weights)
 
 
-def grouped_experts_eager(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str) -> torch.Tensor:
+def grouped_experts_eager(x_flat, topk_indices, topk_gates, fc_weights, proj_weights, act: str, p_drop: float = 0.0,
+                          keep_pairs=None) -> torch.Tensor:
     """Plain PyTorch statement of ``grouped_experts`` (dense over experts; test oracle)."""
     out = torch.zeros_like(x_flat)
+    keep_scale = None
+    if p_drop > 0.0:
+        keep_scale = keep_pairs.to(x_flat.dtype) / (1.0 - p_drop)         # [N, k, C]
     for e, (wf, wp) in enumerate(zip(fc_weights, proj_weights)):
         h = F.linear(x_flat, wf)
         if act == "swiglu":
@@ -444,6 +477,10 @@ def grouped_experts_eager(x_flat, topk_indices, topk_gates, fc_weights, proj_wei
             from .activation import _KINDS
             a = _KINDS[act][1](h)
         y = F.linear(a, wp)
-        w = (topk_gates * (topk_indices == e)).sum(1, keepdim=True)
-        out = out + w.to(y.dtype) * y
+        if keep_scale is None:
+            w = (topk_gates * (topk_indices == e)).sum(1, keepdim=True)
+            out = out + w.to(y.dtype) * y
+        else:
+            w = topk_gates * (topk_indices == e)                          # [N, k]: the slot that chose expert e
+            out = out + (w.unsqueeze(-1).to(y.dtype) * keep_scale).sum(1) * y
     return out

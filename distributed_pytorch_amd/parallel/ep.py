@@ -195,11 +195,12 @@ class ExpertParallelDispatcher:
             return local[0](recv)
         fcs, projs = [m.c_fc.weight for m in local], [m.c_proj.weight for m in local]
         act = local[0].non_linearity
-        if not (moe.training and moe.config.dropout > 0) and ops.grouped_supported(recv, fcs, projs, act):
+        if ops.grouped_supported(recv, fcs, projs, act):
             # grouped MFMA GEMMs over the padded expert-sorted layout: one launch per product for all
-            # local experts, nothing read back to the host
+            # local experts, nothing read back to the host (dropout on the experts' outputs included)
+            p_drop = moe.config.dropout if moe.training else 0.0
             return ops.grouped_experts(recv, row_expert.view(-1, 1), row_weight.view(-1, 1).to(recv.dtype), fcs,
-                                       projs, act)
+                                       projs, act, p_drop=p_drop)
         return None
 
     def mid(self, st):

@@ -1444,3 +1444,39 @@ def test_sampler_step_form_records_the_token_and_advances_the_counters():
     assert (hpos.item(), pos.item(), fill.item(), ticket.item()) == (5, 21, 22, 0)
     assert torch.equal(hist[:, 4], draws[2][:, 0])
     assert not torch.equal(draws[0], draws[1]) and not torch.equal(draws[1], draws[2])
+
+
+@pytest.mark.parametrize("act,U", [("gelu", 512), ("swiglu", 512), ("relu", 384)])
+def test_grouped_experts_with_dropout_matches_eager(act, U):
+    """Dropout on the experts' outputs inside the grouped path (both kernel families): with the mask pinned, output and
+    every gradient equal the dense fp32 statement of the layer."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(31)
+    N, C, E, k, p = 1536, 256, 4, 2, 0.1
+    x = (torch.randn(N, C, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_()
+    W = 2 * U if act == "swiglu" else U
+    fcs = [(torch.randn(W, C, device=DEV) * 0.05).to(torch.bfloat16).requires_grad_() for _ in range(E)]
+    projs = [(torch.randn(C, U, device=DEV) * 0.05).to(torch.bfloat16).requires_grad_() for _ in range(E)]
+    logits = torch.randn(N, E, device=DEV)
+    idx = logits.topk(k, dim=1).indices
+    gates = torch.softmax(logits.gather(1, idx), dim=1).to(torch.bfloat16).requires_grad_()
+    keep = torch.rand(N, k, C, device=DEV) >= p
+    assert ops.grouped_supported(x, fcs, projs, act)
+    out = ops.grouped_experts(x, idx, gates, fcs, projs, act, p_drop=p, keep_pairs=keep)
+    g = torch.randn_like(out)
+    out.backward(g)
+    xr = x.detach().float().requires_grad_()
+    gr = gates.detach().float().requires_grad_()
+    fr = [w.detach().float().requires_grad_() for w in fcs]
+    pr = [w.detach().float().requires_grad_() for w in projs]
+    want = ops.grouped_experts_eager(xr, idx, gr, fr, pr, act, p_drop=p, keep_pairs=keep)
+    want.backward(g.float())
+    assert rel_err(out, want) < 2e-2
+    assert rel_err(x.grad, xr.grad) < 3e-2 and rel_err(gates.grad, gr.grad) < 3e-2
+    for a, b in zip(fcs + projs, fr + pr):
+        assert rel_err(a.grad, b.grad) < 3e-2
+    # the random mask drops about p of the outputs and rescales the rest
+    o1 = ops.grouped_experts(x.detach(), idx, gates.detach(), [w.detach() for w in fcs], [w.detach() for w in projs], act,
+                             p_drop=0.5)
+    o0 = ops.grouped_experts(x.detach(), idx, gates.detach(), [w.detach() for w in fcs], [w.detach() for w in projs], act)
+    assert not torch.equal(o1, o0) and abs(o1.float().mean().item() - o0.float().mean().item()) < 0.05 * o0.float().abs().mean().item() + 1e-3
