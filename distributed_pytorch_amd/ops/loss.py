@@ -24,10 +24,11 @@ group (all-reduce of max / sum-exp / target logit between the two kernel halves)
 
 ``vocab_parallel_linear_cross_entropy``: lm_head + loss of a data-parallel job with the vocabulary
 split over the ranks (``--vocab_parallel``): the hidden rows of all ranks are gathered, every rank
-forms the logits of all rows against its V/W slice of the head weight, the softmax statistics are
-all-reduced, and the input gradient returns through a reduce-scatter. Per-rank FLOPs and logits
-memory equal the replicated head's; what changes is that each rank produces the head's weight
-gradient for its own vocabulary slice only, complete over the global batch.
+forms the logits of all rows against its slice of the head weight (own GEMM kernels), the softmax
+statistics of a chunk travel in one asynchronous all-gather under the next chunk's logits GEMM, and the
+input gradient returns through a reduce-scatter. Per-rank FLOPs equal the replicated head's; each rank
+produces the head's weight gradient for its own vocabulary slice only, complete over the global batch.
+It costs more wire than it saves above V / W tokens per rank (see the function's docstring).
 
 Reference behaviour: ``F.cross_entropy(logits.view(-1, V), targets.view(-1), ignore_index=-1)``
 on the full fp32/amp logits (reference: single-gpu/model.py:687-692).
@@ -285,16 +286,30 @@ def _local_grad(work, targets, lse, tgt_logit, gs, vocab_start, ignore_index):
     return loss_rows, p.to(work.dtype)
 
 
+def vocab_slices(V: int, W: int):
+    """[lo, hi) of the vocabulary rows each of W ranks owns. Large vocabularies are cut at multiples of 128 rows (the
+    own GEMM kernels' contraction / tile granularity), so the last rank's slice is shorter; small ones evenly."""
+    per = (V + W - 1) // W
+    if per >= 1024:
+        per = (per + 127) // 128 * 128
+    return [(min(V, r * per), min(V, (r + 1) * per)) for r in range(W)]
+
+
 class _VocabParallelLinearXentFn(torch.autograd.Function):
+    """Per row chunk of the gathered hidden rows: logits against this rank's vocabulary slice (own NT GEMM) -> local
+    (max, sum-exp, target logit) -> ONE asynchronous all-gather of the three statistics, consumed only after the NEXT
+    chunk's logits GEMM has been queued (two logits buffers alternate) -> combine -> gradient kernel -> dx partial
+    (own NT GEMM on the transposed slice) and dw slice (own weight-gradient kernel, fp32 sums)."""
+
     @staticmethod
     def forward(ctx, x, w, targets, group, ignore_index, chunk_rows):
         comm = _comm()
         W, r = comm.world_size(group), comm.get_rank(group)
         N, C = x.shape
         V = w.shape[0]
-        per = V // W
-        v0 = r * per
-        ws = w[v0:v0 + per]                                  # this rank's vocabulary slice of the tied weight
+        v0, v1 = vocab_slices(V, W)[r]
+        per = v1 - v0
+        ws = w[v0:v1]                                        # this rank's vocabulary slice of the tied weight
         xa = torch.empty(W * N, C, dtype=x.dtype, device=x.device)
         comm.all_gather(xa.view(-1), x.contiguous().view(-1), group=group)
         ta = torch.empty(W * N, dtype=targets.dtype, device=targets.device)
@@ -303,30 +318,81 @@ class _VocabParallelLinearXentFn(torch.autograd.Function):
         dxa = torch.empty_like(xa)
         dws = torch.zeros(per, C, dtype=torch.float32, device=x.device)
         loss_acc = torch.zeros((), dtype=torch.float32, device=x.device)
-        for r0 in range(0, W * N, chunk_rows):
+        gpu = x.is_cuda and x.dtype == torch.bfloat16 and not _library_head() and per > 0
+        own_logits = gpu and bool(ops().gemm_nt_supported(xa[: min(W * N, 16384)], ws, None, None))
+        wst = None
+        if gpu and per % 64 == 0 and per >= 128 and C % 16 == 0:
+            from .linear import transposed_weight
+            wst = transposed_weight(w)[:, v0:v1]             # [C, per]: rows of w^T, row stride V
+        own_dw = gpu and per % 8 == 0 and C % 256 == 0
+        rows_max = min(chunk_rows, W * N)
+        bufs = [torch.empty(rows_max, per, dtype=x.dtype, device=x.device) for _ in range(2 if W * N > chunk_rows else 1)]
+        starts = list(range(0, W * N, chunk_rows))
+
+        def front(ci):
+            """Logits of chunk ci, its local statistics, and the exchange of them (in flight on return)."""
+            r0 = starts[ci]
             r1 = min(W * N, r0 + chunk_rows)
             xc, tc = xa[r0:r1], ta[r0:r1]
-            lg = torch.mm(xc, ws.t())
-            mx, sm, tg = _local_stats(lg, tc, v0, ignore_index)
-            gmx = mx.clone()
-            comm.all_reduce(gmx, op=dist.ReduceOp.MAX, group=group)
-            packed = torch.stack([sm * torch.exp(mx - gmx), tg])
-            comm.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-            lse = gmx + torch.log(packed[0])
-            loss_rows, dlg = _local_grad(lg, tc, lse, packed[1], gs, v0, ignore_index)
-            loss_acc += loss_rows.sum()
-            torch.mm(dlg, ws, out=dxa[r0:r1])                # partial over this slice; summed by the reduce-scatter
-            if x.is_cuda and x.dtype == torch.bfloat16:
-                torch.addmm(dws, dlg.t(), xc, out_dtype=torch.float32, out=dws)   # bf16 operands, fp32 sum
+            lg = bufs[ci % len(bufs)][: r1 - r0]
+            if per == 0:
+                mx = torch.full((r1 - r0,), float("-inf"), device=x.device)
+                sm = torch.zeros(r1 - r0, device=x.device)
+                tg = torch.zeros(r1 - r0, device=x.device)
             else:
-                dws.addmm_(dlg.t().float(), xc.float())
+                if own_logits and ops().gemm_nt_supported(xc, ws, None, None):
+                    ops().gemm_nt_into(xc, ws, lg)
+                else:
+                    torch.mm(xc, ws.t(), out=lg)
+                mx, sm, tg = _local_stats(lg, tc, v0, ignore_index)
+            mine = torch.stack([mx.float(), sm.float(), tg.float()]).contiguous()          # [3, rows]
+            every = torch.empty(W, 3, r1 - r0, dtype=torch.float32, device=x.device)
+            work = comm.all_gather(every.view(-1), mine.view(-1), group=group, async_op=True)
+            return (r0, r1, xc, tc, lg, every, work)
+
+        def back(st):
+            r0, r1, xc, tc, lg, every, work = st
+            work.wait()
+            gmx = every[:, 0].max(dim=0).values
+            sm = (every[:, 1] * torch.exp(every[:, 0] - gmx)).sum(dim=0)      # exp(-inf - finite) = 0 for empty slices
+            lse = gmx + torch.log(sm)
+            tgt_logit = every[:, 2].sum(dim=0)
+            if per == 0:
+                valid = tc != ignore_index
+                return torch.where(valid, lse - tgt_logit, torch.zeros_like(lse)).sum()
+            loss_rows, dlg = _local_grad(lg, tc, lse, tgt_logit, gs, v0, ignore_index)
+            if wst is not None and ops().gemm_nt_supported(dlg, wst, None, None):
+                ops().gemm_nt_into(dlg, wst, dxa[r0:r1])     # partial over this slice; summed by the reduce-scatter
+            else:
+                torch.mm(dlg, ws.to(dlg.dtype), out=dxa[r0:r1])
+            rows = r1 - r0
+            m64 = rows // 64 * 64 if (own_dw and rows >= 1024) else 0
+            if m64:
+                ops().wgrad2_accum(dlg[:m64], xc[:m64], dws)
+            if m64 < rows:
+                if x.is_cuda and x.dtype == torch.bfloat16:
+                    torch.addmm(dws, dlg[m64:].t(), xc[m64:], out_dtype=torch.float32, out=dws)   # bf16 operands, fp32 sum
+                else:
+                    dws.addmm_(dlg[m64:].t().float(), xc[m64:].float())
+            return loss_rows.sum()
+
+        pending = None
+        for ci in range(len(starts)):
+            st = front(ci)                      # chunk ci's logits GEMM is queued before chunk ci-1's statistics are waited for
+            if pending is not None:
+                loss_acc += back(pending)
+            pending = st
+        if pending is not None:
+            loss_acc += back(pending)
+        if per == 0:
+            dxa.zero_()
         dx = torch.empty_like(x)
         comm.reduce_scatter(dx.view(-1), dxa.view(-1), group=group)
         # The data-parallel engines average parameter gradients over the ranks and expect each rank's
         # backward to start from the gradient of ITS loss: both are W times what the global loss gives.
         dx.mul_(W)
         dw = torch.zeros_like(w)
-        dw[v0:v0 + per] = (dws * W).to(w.dtype)
+        dw[v0:v1] = (dws * W).to(w.dtype)
         ctx.save_for_backward(dx, dw)
         return loss_acc * gs[0]
 
@@ -337,10 +403,16 @@ class _VocabParallelLinearXentFn(torch.autograd.Function):
 
 
 def vocab_parallel_linear_cross_entropy(x: torch.Tensor, w: torch.Tensor, targets: torch.Tensor, group=None,
-                                        ignore_index: int = IGNORE_INDEX, chunk_rows: int = 8192) -> torch.Tensor:
+                                        ignore_index: int = IGNORE_INDEX, chunk_rows: int = 65536) -> torch.Tensor:
     """Global-batch mean cross-entropy of ``x @ w.T`` with the vocabulary dimension of ``w [V, C]`` split over
-    the ranks of ``group`` (every rank holds the full tied weight and uses rows ``[r V/W, (r+1) V/W)``)."""
-    W = _comm().world_size(group)
-    assert w.shape[0] % W == 0, f"vocabulary {w.shape[0]} does not split over {W} ranks"
+    the ranks of ``group`` (every rank holds the full tied weight and uses the rows ``vocab_slices(V, W)[rank]``).
+
+    Wire cost per rank and step against the replicated head (N = tokens per rank, bf16): the gather of the hidden rows
+    and the reduce-scatter of their gradient move ``2 (W - 1) N C 2`` bytes, the statistics ``12 (W - 1) N`` bytes; the
+    replicated head moves none of that and instead all-reduces the head's share of the tied gradient,
+    ``2 (W - 1) / W V C 2`` bytes. The split head therefore saves wire only below ``N = V / W`` tokens per rank
+    (6288 at W = 8 for GPT-2's vocabulary: a micro-batch of 6 sequences); with tied embeddings the [V, C] gradient
+    of the embedding still has to be reduced, so in practice it saves none. What it does buy is memory: the logits
+    chunk is W times narrower."""
     x2 = x.reshape(-1, x.shape[-1])
     return _VocabParallelLinearXentFn.apply(x2, w, targets.reshape(-1), group, ignore_index, int(chunk_rows))

@@ -82,7 +82,7 @@ class Engine(nn.Module):
         self._dist = not comm._single(group)   # collectives are really issued (always when world > 1)
         if vocab_parallel and self._dist:
             V = getattr(getattr(model, "config", None), "vocab_size", 0)
-            assert V and V % self.world == 0, f"--vocab_parallel: vocabulary {V} does not split over {self.world} ranks"
+            assert V and V >= self.world, f"--vocab_parallel: vocabulary {V} does not split over {self.world} ranks"
             model.vocab_parallel = (group,)
         self.rank = comm.get_rank(group)
         self.weight_decay = weight_decay

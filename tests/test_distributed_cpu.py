@@ -166,6 +166,43 @@ def test_vocab_parallel_cross_entropy_matches_full():
         assert gerr < 1e-6
 
 
+def _vpl_worker(rank, world):
+    import torch.nn.functional as F
+    from distributed_pytorch_amd.ops import vocab_parallel_linear_cross_entropy
+    from distributed_pytorch_amd.ops.loss import vocab_slices
+    torch.manual_seed(0)
+    N, C, V = 10, 16, 40
+    xs = torch.randn(world, N, C)
+    w = torch.randn(V, C) * 0.3
+    ts = torch.randint(0, V, (world, N))
+    ts[:, ::4] = -1
+    # reference: the global-batch loss on one process; a rank's gradients are W times its share (the engines average)
+    xr = xs.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    ref = F.cross_entropy((xr.view(-1, C) @ wr.t()), ts.view(-1), ignore_index=-1)
+    ref.backward()
+    x = xs[rank].clone().requires_grad_()
+    wl = w.clone().requires_grad_()
+    loss = vocab_parallel_linear_cross_entropy(x, wl, ts[rank], chunk_rows=8)     # 30 gathered rows: 4 chunks, 2 buffers
+    loss.backward()
+    lo, hi = vocab_slices(V, world)[rank]
+    own = torch.zeros_like(w)
+    own[lo:hi] = wr.grad[lo:hi] * world
+    return (abs(loss.item() - ref.item()), (x.grad - xr.grad[rank] * world).abs().max().item(),
+            (wl.grad - own).abs().max().item(), (lo, hi))
+
+
+def test_vocab_parallel_head_with_uneven_slices_and_pipelined_chunks():
+    """Three ranks, a vocabulary of 40 (slices 14 / 14 / 12), row chunks smaller than the gathered batch: the loss is
+    the global one, dx the rank's rows of the global gradient, dw this rank's vocabulary rows of it (times W)."""
+    from distributed_pytorch_amd.ops.loss import vocab_slices
+    assert vocab_slices(40, 3) == [(0, 14), (14, 28), (28, 40)]
+    assert vocab_slices(50304, 8) == [(i * 6400, min(50304, (i + 1) * 6400)) for i in range(8)]
+    assert vocab_slices(50304, 1) == [(0, 50304)]
+    for dl, dxe, dwe, _ in run_distributed(_vpl_worker, 3):
+        assert dl < 1e-5 and dxe < 1e-5 and dwe < 1e-5
+
+
 def _launch_order_worker(rank, world):
     """Record the order in which the DDP buckets are reduced and how many had left when backward ended."""
     from distributed_pytorch_amd.parallel.ddp import DDPEngine
