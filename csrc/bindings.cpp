@@ -876,7 +876,9 @@ void wgrad2_direct(const Tensor& dy, const Tensor& x, Tensor dw_acc, const std::
   }
   const int splits = dpa::wgrad2_splits((int)M, (int)N, (int)K);
   // one split of the 256 x 256 kernel: it adds into the gradient itself (no slab, no fold)
-  const bool direct = dpa::wgrad2_direct_ok((int)M, (int)N, (int)K) && dw_acc.is_contiguous();
+  // (fp32 destinations only: the read-modify-write of a bf16 destination from the accumulator layout is 2-byte
+  // accesses, measured 0.5-1 % slower on the GPT-2-1.3B step than slab + fold)
+  const bool direct = dpa::wgrad2_direct_ok((int)M, (int)N, (int)K) && dw_acc.is_contiguous() && !is_bf16(dw_acc);
   Tensor slabs = direct ? Tensor() : at::empty({splits, N, K}, dy.options().dtype(at::kFloat));
   float* slab_ptr = direct ? nullptr : slabs.data_ptr<float>();
   void* dptr = direct ? dw_acc.data_ptr() : nullptr;

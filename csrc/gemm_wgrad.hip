@@ -23,6 +23,7 @@
 //
 // Replaces the dW GEMMs that `nn.Linear`'s backward issues implicitly in the reference
 // (reference: single-gpu/model.py:112-114,373-384,559).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "mfma_tiles.h"
@@ -626,11 +627,26 @@ void wgrad2_force_splits(int s) { g_wgrad2_force_splits = s; }
 int wgrad2_splits(int M, int N, int K) {
   if (use_wgrad3(M, N, K) && g_wgrad2_force_splits > 0) return g_wgrad2_force_splits;
   if (use_wgrad3(M, N, K)) {
+    // Row splits of the 256 x 256 kernel: the count that minimises (rounds of 256 workgroups) x (time of one split of
+    // a tile) + (traffic of the per-split fp32 slabs and their fold). 192 tiles (dW[6144, 2048]) run as 4 splits =
+    // 3 full rounds instead of one round on three quarters of the CUs; 36 tiles as 7 splits; 256 tiles as one.
     const int t3 = ((N + 255) / 256) * (K / 256);
-    int s3 = 256 / t3;                   // one workgroup per CU
-    if (s3 > M / 512) s3 = M / 512;      // at least 8 LDS tiles per workgroup
-    if (s3 > 64) s3 = 64;
-    return s3 < 1 ? 1 : s3;
+    int smax = M / 512;                  // at least 16 LDS slots per workgroup
+    if (smax > 64) smax = 64;
+    if (smax < 1) smax = 1;
+    const double tile_s = 2.0 * M * 256.0 * 256.0 / 4.5e12;            // one tile over all rows on one CU (1150 TF chip-wide)
+    const double slab_s = 2.0 * 4.0 * (double)N * (double)K / 4.0e12;  // a slab written and read back at 4 TB/s
+    int best = 1;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= smax; ++sp) {
+      const int rounds = (t3 * sp + 255) / 256;
+      const double t = rounds * tile_s / sp + sp * slab_s;
+      if (t < best_t * 0.995) {          // ties go to the smaller count
+        best_t = t;
+        best = sp;
+      }
+    }
+    return best;
   }
   const int tiles = ((N + kW2N - 1) / kW2N) * (K / kW2K);
   int s = 512 / tiles;   // one round of the workgroups that fit (two per CU)
@@ -649,7 +665,9 @@ bool wgrad2_fuses_bias(int M, int N, int K) { return use_wgrad3(M, N, K); }
 // rows of the fp32 [rows, N] partial bias sums the fused form writes (every one is written: sum them all)
 int wgrad2_bias_slabs(int M, int N, int K) { return wgrad2_splits(M, N, K) * 2 * (K / 256); }
 
-bool wgrad2_direct_ok(int M, int N, int K) { return use_wgrad3(M, N, K) && wgrad2_splits(M, N, K) == 1; }
+bool wgrad2_direct_ok(int M, int N, int K) {
+  return use_wgrad3(M, N, K) && wgrad2_splits(M, N, K) == 1;
+}
 
 void wgrad2_gemm(const void* dy, const void* x, float* ws, int M, int N, int K, long long ldy, long long ldx,
                  int splits, hipStream_t st, float* bias_slabs, void* direct, bool direct_bf16) {

@@ -101,9 +101,13 @@ def test_every_engine_trains_on_gpu(mode):
     assert sd["lm_head.weight"].dtype == torch.float32 and sd["lm_head.weight"].shape == (1024, 256)
 
 
-def test_generate_on_gpu_matches_full_forward():
+@pytest.mark.parametrize("name", ["gqa_rope_swiglu", "mla_rope_wide"])
+def test_generate_on_gpu_matches_full_forward(name):
+    """Incremental decoding over the KV cache reproduces the full forward pass. The wide latent configuration has no
+    static-cache decode path (its absorbed key is 384 wide): its cache path runs the absorbed form eagerly, while its
+    cache-free forward in evaluation mode is the absorbed form too, so the two must agree."""
     torch.manual_seed(2)
-    cfg = LLMconfig(**BASE, **VARIANTS["gqa_rope_swiglu"]).finalize()
+    cfg = LLMconfig(**{**BASE, **VARIANTS[name]}).finalize()
     m = LLM(cfg).cuda().to(torch.bfloat16).eval()
     assert m.rope_cos.dtype == torch.float32 and m.freqs_cis.is_complex()   # tables survive the cast
     idx = torch.randint(0, cfg.vocab_size, (2, 40), device="cuda")
