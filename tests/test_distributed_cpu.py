@@ -74,6 +74,11 @@ def _worker(rank, world, mode, cfg_name, n_steps, global_b, accum):
     elif mode == "fsdp_keep":
         from distributed_pytorch_amd.parallel.fsdp import FSDPEngine
         eng = FSDPEngine(model, reshard_after_forward=False, **kw)
+    elif mode.startswith("fsdp_p"):           # fsdp_p<prefetch>i<inflight>: the tunables of --fsdp_prefetch / --fsdp_inflight
+        from distributed_pytorch_amd.parallel.fsdp import FSDPEngine
+        pf, fl = mode[len("fsdp_p"):].split("i")
+        eng = FSDPEngine(model, prefetch=int(pf), inflight=int(fl), **kw)
+        assert eng.prefetch == int(pf) and eng.inflight == int(fl)
     assert (eng.module.vocab_parallel is not None) == ("vocab_parallel" in kw)
     _train(eng, _batches(cfg, n_steps, global_b, accum), rank, world, accum)
     sd = eng.state_dict()
@@ -92,6 +97,16 @@ def test_matches_single_process(mode, cfg_name):
         if want[k].is_complex():
             assert torch.allclose(torch.view_as_real(got[k]), torch.view_as_real(want[k]))
             continue
+        assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
+
+
+@pytest.mark.parametrize("mode", ["fsdp_p0i1", "fsdp_p2i3", "fsdp_p3i1"])
+def test_fsdp_prefetch_and_inflight_settings_match_single_process(mode):
+    """No gather ahead and one reduce-scatter in flight, two / three units gathered ahead with up to three
+    reduce-scatters in flight: the same trajectory as one process in every setting."""
+    want = _single_reference("gpt")
+    got = run_distributed(_worker, 2, mode, "gpt", 3, 4, 2)[0]
+    for k in want:
         assert torch.allclose(got[k].float(), want[k].float(), rtol=2e-4, atol=2e-5), f"{mode}: {k} differs"
 
 
