@@ -852,12 +852,13 @@ std::tuple<Tensor, Tensor> wgrad2_slabs_bias(const Tensor& dy, const Tensor& x) 
   return {slabs, colsum(dy)};
 }
 
-void scale_unless(Tensor x, const Tensor& g, double expected) {
+void scale_unless(Tensor x, const Tensor& g, const Tensor& expected) {
   check_act(x, "x");
   TORCH_CHECK(x.is_contiguous() && x.numel() % 8 == 0, "scale_unless: contiguous tensor of a multiple of 8 elements");
   TORCH_CHECK(g.is_cuda() && g.scalar_type() == at::kFloat && g.numel() == 1, "scale_unless: g is one fp32 value on the device");
-  TORCH_CHECK(expected != 0.0, "scale_unless: expected factor must not be zero");
-  dpa::scale_unless(x.data_ptr(), x.numel(), is_bf16(x), g.data_ptr<float>(), (float)expected, cur_stream());
+  TORCH_CHECK(expected.is_cuda() && expected.scalar_type() == at::kFloat && expected.numel() == 1,
+              "scale_unless: expected is one fp32 value on the device");
+  dpa::scale_unless(x.data_ptr(), x.numel(), is_bf16(x), g.data_ptr<float>(), expected.data_ptr<float>(), cur_stream());
 }
 
 // dw_acc [N, K] += dy^T x and, when given, db_acc [N] += column sums of dy: the weight-gradient GEMM
@@ -1262,7 +1263,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");
   m.def("wgrad2(Tensor dy, Tensor x) -> Tensor");
   m.def("wgrad2_set_stages(int s) -> ()");
-  m.def("scale_unless(Tensor(a!) x, Tensor g, float expected) -> ()");
+  m.def("scale_unless(Tensor(a!) x, Tensor g, Tensor expected) -> ()");
   m.def("wgrad2_force_splits(int s) -> ()");
   m.def("clear_last_error() -> int");
   m.def("wgrad2_slabs(Tensor dy, Tensor x) -> Tensor");

@@ -118,8 +118,8 @@ void wgrad_gemm(const void* dy, const void* x, float* ws, float* dbias, int M, i
 // splits == 0: one pass that adds into ws[N*K].
 bool wgrad2_ok(int M, int N, int K);
 int wgrad2_splits(int M, int N, int K);
-// x (n elements, n % 8 == 0, 16-byte aligned) *= g[0] / expected unless g[0] == expected
-void scale_unless(void* x, long long n, bool is_bf16, const float* g, float expected, hipStream_t st);
+// x (n elements, n % 8 == 0, 16-byte aligned) *= g[0] / expected[0] unless the two are equal
+void scale_unless(void* x, long long n, bool is_bf16, const float* g, const float* expected, hipStream_t st);
 void wgrad2_set_stages(int s);
 void wgrad2_force_splits(int s);
 // bias_slabs (optional, only when wgrad2_fuses_bias(M, N, K) and splits > 0): fp32 [wgrad2_bias_slabs(M, N, K), N]

@@ -52,13 +52,13 @@ void colsum(const void* x, float* out, long long M, int N, long long ld, bool is
     hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, st, (const float*)x, out, M, N, ld, (int)rpb);
 }
 
-// x *= g / expected, unless the two are equal (then every thread leaves after reading g: no pass over x). The fused
+// x *= g[0] / expected[0] (both read from device memory), unless the two are equal (then every thread leaves after reading g: no pass over x). The fused
 // head loss writes its gradients already multiplied by the factor the caller said the loss would be scaled by; its
 // backward only has to correct them when the incoming gradient turns out to be something else.
 template <typename T>
 __global__ __launch_bounds__(256) void scale_unless_kernel(T* __restrict__ x, long long nvec, const float* __restrict__ g,
-                                                           float expected) {
-  const float r = g[0] / expected;
+                                                           const float* __restrict__ expected) {
+  const float r = g[0] / expected[0];
   if (r == 1.0f) return;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
     float v[8];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void scale_unless_kernel(T* __restrict__ x, lo
   }
 }
 
-void scale_unless(void* x, long long n, bool is_bf16, const float* g, float expected, hipStream_t st) {
+void scale_unless(void* x, long long n, bool is_bf16, const float* g, const float* expected, hipStream_t st) {
   const long long nvec = n >> 3;
   if (nvec == 0) return;
   long long blocks = (nvec + 255) / 256;

@@ -158,7 +158,9 @@ class _LinearXentFn(torch.autograd.Function):
         if ws is not None:
             dw = ws.to(x.dtype)
         ctx.save_for_backward(dx, dw)
-        ctx.expected_grad = expected_grad
+        # the factor the stored gradients currently carry (device scalar: a second backward over a retained graph
+        # rescales from what the first one left, not from the announced factor again)
+        ctx.applied = torch.full((1,), float(expected_grad), dtype=torch.float32, device=x.device)
         return loss_acc * gs[0]     # the loss carries 1 / valid targets only; expected_grad went into the gradients
 
     @staticmethod
@@ -169,9 +171,10 @@ class _LinearXentFn(torch.autograd.Function):
             if t is None:
                 continue
             if t.is_cuda and t.numel() % 8 == 0 and t.is_contiguous() and t.data_ptr() % 16 == 0:
-                ops().scale_unless(t, g32, float(ctx.expected_grad))
+                ops().scale_unless(t, g32, ctx.applied)
             else:
-                t.mul_((g32[0] / ctx.expected_grad).to(t.dtype))
+                t.mul_((g32[0] / ctx.applied[0]).to(t.dtype))
+        ctx.applied.copy_(g32)
         return dx, dw, None, None, None, None
 
 

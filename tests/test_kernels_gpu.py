@@ -176,6 +176,23 @@ def test_linear_cross_entropy_matches_unfused(N, C, chunk, expected):
     assert rel_err(w.grad, dwr) < 2e-2
 
 
+def test_linear_cross_entropy_backward_twice_over_a_retained_graph():
+    """The stored gradients are rescaled from the factor they carry, so a second backward with another incoming
+    gradient gives that gradient's result (accumulated on top of the first)."""
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(5)
+    N, C, V = 2048, 256, 1024
+    x = (torch.randn(N, C, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_()
+    w = (torch.randn(V, C, device=DEV) * 0.05).to(torch.bfloat16).requires_grad_()
+    tgt = torch.randint(0, V, (N,), device=DEV)
+    loss = ops.linear_cross_entropy(x, w, tgt, expected_grad=0.5)
+    (loss * 0.5).backward(retain_graph=True)
+    g1 = x.grad.clone()
+    x.grad = None
+    (loss * 2.0).backward()
+    assert rel_err(x.grad, g1.float() * 4.0) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_embedding_fwd_bwd(dtype):
     from distributed_pytorch_amd import ops
