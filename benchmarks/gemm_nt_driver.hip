@@ -352,6 +352,19 @@ int main(int argc, char** argv) {
     run_case(M, 3072, 768, 1, false, false, 20);
     run_case(M, 3072, 768, 2, false, false, 20);
   }
+  if (!strcmp(mode, "gelu")) {   // the GELU epilogue against the plain one, stores on / dropped, 2 us start skew (build with -DDPA_GELU_VARIANT=n)
+    const int M = 65536;
+    if (argc > 2 && atoi(argv[2])) run_case(33000, 3072, 768, 1, false, true, 0);
+    for (int v : {0, 2}) {
+      printf("---- stores %s\n", v ? "dropped" : "on");
+      dpa::gemm_nt_set_variant(v | (200 << 8));
+      for (int rep = 0; rep < 2; ++rep) {
+        run_case(M, 3072, 768, 0, false, false, 30);
+        run_case(M, 3072, 768, 1, false, false, 30);
+      }
+    }
+    dpa::gemm_nt_set_variant(0);
+  }
   if (!strcmp(mode, "skew")) {
     const int M = 65536;
     for (int ticks : {0, 200, 400, 600, 800}) {   // 100 MHz ticks per group step: 0 .. 8 us

@@ -108,7 +108,7 @@ __device__ __forceinline__ void barrier() {
 // Exact-erf GELU and its derivative. erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
 // Phi(-|x|) = 0.5 * t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2).
 #ifndef DPA_GELU_VARIANT
-#define DPA_GELU_VARIANT 1   // 1: pairs of values through the explicitly packed form (measured 1.5 % faster on the fc shape)
+#define DPA_GELU_VARIANT 2   // 0: one value at a time; 1: pairs in packed fp32 arithmetic; 2: pairs, sign by bit copy; 3: 2 + one reciprocal per pair
 #endif
 __device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) {
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678f, 1.0f));
@@ -126,7 +126,13 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& act, float& dact) 
 // The same on two values with the plain arithmetic in packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& act, f32x2& dact) {
+#if DPA_GELU_VARIANT >= 10
+  // timing-only ablations: 10 = the transcendental instructions replaced by copies, 11 = no arithmetic at all
+  if (DPA_GELU_VARIANT == 11) { act = x; dact = x; return; }
+#endif
+#if DPA_GELU_VARIANT == 1
   const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
   const f32x2 one = {1.0f, 1.0f};
   const f32x2 u = pk_fma(ax, f32x2{0.3275911f * 0.70710678f, 0.3275911f * 0.70710678f}, one);
@@ -142,6 +148,40 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& act, f32x2& dact)
   const f32x2 phi = {x[0] >= 0.f ? hm[0] : h[0], x[1] >= 0.f ? hm[1] : h[1]};
   act = x * phi;
   dact = pk_fma(x * e, f32x2{0.3989422804f, 0.3989422804f}, phi);
+#else
+  // Phi(x) = 0.5 + sign(x) (0.5 - Phi(-|x|)): the sign goes in by a bit copy instead of a compare and a select per
+  // value, |x| rides in the fused multiply-add's operand modifier, the exponent's factor is split over both
+  // factors of the square.
+  const float k1 = 0.3275911f * 0.70710678f;
+  const f32x2 u = {fmaf(fabsf(x[0]), k1, 1.0f), fmaf(fabsf(x[1]), k1, 1.0f)};
+#if DPA_GELU_VARIANT == 3
+  const float r = __builtin_amdgcn_rcpf(u[0] * u[1]);   // one reciprocal for both: 1 / u0 = u1 / (u0 u1)
+  const f32x2 t = f32x2{u[1], u[0]} * splat2(r);
+#elif DPA_GELU_VARIANT == 10
+  const f32x2 t = u;
+#else
+  const f32x2 t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+#endif
+  // e = exp(-x^2 / 2) / sqrt(2 pi), the density itself (the constant rides in the exponent; the polynomial's
+  // coefficients carry its inverse)
+  const f32x2 s = x * splat2(0.84932180028f);   // sqrt(0.5 log2(e))
+  const f32x2 xx = pk_fma(s, s, splat2(1.32574806473f));   // + log2(sqrt(2 pi))
+#if DPA_GELU_VARIANT == 10
+  const f32x2 e = xx;
+#else
+  const f32x2 e = {__builtin_amdgcn_exp2f(-xx[0]), __builtin_amdgcn_exp2f(-xx[1])};
+#endif
+  constexpr float kc = 0.5f * 2.50662827463f;   // 0.5 sqrt(2 pi)
+  f32x2 poly = pk_fma(t, splat2(kc * 1.061405429f), splat2(kc * -1.453152027f));
+  poly = pk_fma(poly, t, splat2(kc * 1.421413741f));
+  poly = pk_fma(poly, t, splat2(kc * -0.284496736f));
+  poly = pk_fma(poly, t, splat2(kc * 0.254829592f));
+  const f32x2 tp = poly * t;
+  const f32x2 q = pk_fma(-e, tp, splat2(0.5f));   // 0.5 - Phi(-|x|) >= 0
+  const f32x2 phi = f32x2{__builtin_copysignf(q[0], x[0]), __builtin_copysignf(q[1], x[1])} + splat2(0.5f);
+  act = x * phi;
+  dact = pk_fma(x, e, phi);
+#endif
 }
 
 // vmcnt immediates of the four phases of a K-tile, and whether phases 0 and 1 issue a unit refill
@@ -698,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
           for (int T = 0; T < 4; ++T)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * T + e] = acc[mh][mt][T][e] + bias_at(4 * T + e);
+            for (int e = 0; e < 4; ++e) v[4 * T + e] = BIAS ? acc[mh][mt][T][e] + bias_at(4 * T + e) : acc[mh][mt][T][e];   // (x + 0.0f is an instruction: -0.0)
           if (EPI == kEpiRope) {
             if (rot) {
 #pragma unroll
@@ -791,7 +831,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
           if (EPI == kEpiGelu) {
             u32x4 g0, g1;
             float a[16], d[16];
-#if DPA_GELU_VARIANT == 1
+#if DPA_GELU_VARIANT >= 1
 #pragma unroll
             for (int j = 0; j < 16; j += 2) {
               f32x2 a2, d2;
