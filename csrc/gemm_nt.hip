@@ -769,12 +769,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float a0 = lo_bf16(x0[j]), a1 = hi_bf16(x0[j]), a2 = lo_bf16(x1[j]), a3 = hi_bf16(x1[j]);
+              // (pairs in packed fp32 arithmetic: half the multiply / add instructions)
+              const f32x2 xa = {lo_bf16(x0[j]), hi_bf16(x0[j])}, xb = {lo_bf16(x1[j]), hi_bf16(x1[j])};
+              f32x2 va = {v[2 * j], v[2 * j + 1]}, vb = {v[8 + 2 * j], v[8 + 2 * j + 1]};
               if (EPI == kEpiMul) {
-                v[2 * j] *= a0; v[2 * j + 1] *= a1; v[8 + 2 * j] *= a2; v[8 + 2 * j + 1] *= a3;
+                va *= xa; vb *= xb;
               } else {
-                v[2 * j] += a0; v[2 * j + 1] += a1; v[8 + 2 * j] += a2; v[8 + 2 * j + 1] += a3;
+                va += xa; vb += xb;
               }
+              v[2 * j] = va[0]; v[2 * j + 1] = va[1]; v[8 + 2 * j] = vb[0]; v[8 + 2 * j + 1] = vb[1];
             }
           }
           if (EPI == kEpiSwiglu) {
