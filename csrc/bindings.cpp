@@ -1239,6 +1239,20 @@ Tensor transpose_bf16(const Tensor& x) {
   return out;
 }
 
+// Equally shaped contiguous bf16 matrices [R, C] at the addresses in `in_ptrs` -> their transposes at `out_ptrs`
+// (int64 device tensors; the caller vouches for the addresses: 16-byte aligned, R x C bf16 behind each).
+void transpose_bf16_many(const Tensor& in_ptrs, const Tensor& out_ptrs, int64_t R, int64_t C) {
+  TORCH_CHECK(in_ptrs.is_cuda() && out_ptrs.is_cuda() && in_ptrs.scalar_type() == at::kLong &&
+                  out_ptrs.scalar_type() == at::kLong && in_ptrs.dim() == 1 && in_ptrs.is_contiguous() &&
+                  out_ptrs.is_contiguous() && in_ptrs.numel() == out_ptrs.numel(),
+              "transpose_bf16_many: two int64 device vectors of equal length");
+  TORCH_CHECK(R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && in_ptrs.numel() <= 65535,
+              "transpose_bf16_many: R, C multiples of 8, at most 65535 matrices");
+  dpa::transpose_bf16_many(reinterpret_cast<const long long*>(in_ptrs.data_ptr<int64_t>()),
+                           reinterpret_cast<const long long*>(out_ptrs.data_ptr<int64_t>()), (int)in_ptrs.numel(), (int)R,
+                           (int)C, cur_stream());
+}
+
 TORCH_LIBRARY(dpa, m) {
   m.def("gemm_nt(Tensor a, Tensor b, Tensor? bias, int epi, Tensor? aux) -> (Tensor, Tensor?)");
   m.def("gemm_nt_supported(Tensor a, Tensor b, Tensor? bias, Tensor? aux) -> bool");
@@ -1248,6 +1262,7 @@ TORCH_LIBRARY(dpa, m) {
   m.def("gemm_nt_set_variant(int v) -> ()");
   m.def("grouped_wgrad_use_wgrad3(bool on, bool any_size=False) -> ()");
   m.def("transpose_bf16(Tensor x) -> Tensor");
+  m.def("transpose_bf16_many(Tensor in_ptrs, Tensor out_ptrs, int R, int C) -> ()");
   m.def("ws_to_many(Tensor ws, Tensor dst_ptrs, bool accumulate, bool out_bf16) -> ()");
   m.def("wgrad2_slabs_bias(Tensor dy, Tensor x) -> (Tensor, Tensor)");
   m.def("wgrad2_direct(Tensor dy, Tensor x, Tensor(a!) dw_acc, Tensor(b!)? db_acc) -> ()");
@@ -1331,6 +1346,7 @@ TORCH_LIBRARY_IMPL(dpa, CUDA, m) {
   m.impl("gemm_nt_into", gemm_nt_into);
   m.impl("gemm_nt_grouped", gemm_nt_grouped);
   m.impl("transpose_bf16", transpose_bf16);
+  m.impl("transpose_bf16_many", transpose_bf16_many);
   m.impl("wgrad2_slabs_bias", wgrad2_slabs_bias);
   m.impl("wgrad2_direct", wgrad2_direct);
   m.impl("moe_topk_gate", moe_topk_gate);

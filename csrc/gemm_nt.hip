@@ -893,8 +893,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
 }
 
 // out[C, R] = in[R, C]^T through a padded 64 x 64 LDS tile (16-byte global accesses both ways).
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                             int R, int C) {
+__device__ __forceinline__ void transpose_tile(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C) {
   __shared__ bf16_t tile[64][72];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -921,10 +920,28 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int R, int C) {
+  transpose_tile(in, out, R, C);
+}
+
+// The same for a list of equally shaped matrices in one launch (blockIdx.z = matrix): the transposed copies of
+// all layers' weights are refreshed together after an optimizer step.
+__global__ __launch_bounds__(256) void transpose_bf16_many_kernel(const long long* __restrict__ in,
+                                                                  const long long* __restrict__ out, int R, int C) {
+  transpose_tile(reinterpret_cast<const bf16_t*>(in[blockIdx.z]), reinterpret_cast<bf16_t*>(out[blockIdx.z]), R, C);
+}
+
 void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st) {
   if (R == 0 || C == 0) return;
   const dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, R, C);
+}
+
+void transpose_bf16_many(const long long* in_ptrs, const long long* out_ptrs, int count, int R, int C, hipStream_t st) {
+  if (R == 0 || C == 0 || count == 0) return;
+  const dim3 grid((C + 63) / 64, (R + 63) / 64, count), block(256);
+  hipLaunchKernelGGL(transpose_bf16_many_kernel, grid, block, 0, st, in_ptrs, out_ptrs, R, C);
 }
 
 bool gemm_nt_ok(long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long ld_aux,

@@ -195,6 +195,8 @@ long long gemm_nt_rows_per_launch(const GemmNtArgs& a, int epi);
 void gemm_nt_set_variant(int v);   // benchmark knob, see csrc/gemm_nt.hip
 // out[C, R] = in[R, C]^T (bf16, R % 8 == 0 and C % 8 == 0, contiguous).
 void transpose_bf16(const void* in, void* out, int R, int C, hipStream_t st);
+// count equally shaped matrices (device arrays of addresses) in one launch; count <= 65535
+void transpose_bf16_many(const long long* in_ptrs, const long long* out_ptrs, int count, int R, int C, hipStream_t st);
 
 // ---- Decode-step linear layer (csrc/decode.hip) ------------------------------------------------------
 // y[B, N] = act(LN(x)[B, K] * w[N, K]^T + bias) + residual for B <= 64 rows (bf16, fp32 accumulation), one launch.

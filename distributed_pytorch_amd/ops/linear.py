@@ -105,6 +105,7 @@ def _direct_bias_target(b_param):
 GEMM_MIN_ROWS = int(os.environ.get("DPA_GEMM_MIN_ROWS", 512))   # below this the 256-row tiles are mostly padding
 _EPI_NONE, _EPI_GELU, _EPI_MUL, _EPI_ADD, _EPI_SWIGLU, _EPI_DSWIGLU = 0, 1, 2, 3, 4, 5
 _WT_CACHE: dict = {}
+_BATCH_TRANSPOSES = os.environ.get("DPA_BATCH_TRANSPOSES", "1") == "1"
 _WEIGHTS_EPOCH = 0
 
 
@@ -113,6 +114,40 @@ def bump_weights_epoch() -> None:
     fused optimizer kernel): cached transposed weights are stale from here on."""
     global _WEIGHTS_EPOCH
     _WEIGHTS_EPOCH += 1
+
+
+_PTR_TABLES: dict = {}
+
+
+def _refresh_resident_transposes() -> None:
+    """One launch per weight shape for every cached transpose that went stale with the last optimizer step.
+
+    Only weights whose owner keeps them at a fixed address for the whole run take part (``Parameter._dpa_resident``,
+    set by the flat groups of the data-parallel engines; the units of the fully sharded engine release and re-gather
+    their storage, so a stale entry of theirs may have nothing valid behind it right now). The transposes are written
+    into the buffers the cache already holds, whose addresses stay in a device table per shape."""
+    by_shape: dict = {}
+    for key, (stamp, wt, ref) in _WT_CACHE.items():
+        w = ref()
+        if w is None or not getattr(w, "_dpa_resident", False) or w.dtype != torch.bfloat16 or not w.is_contiguous():
+            continue
+        now = (_WEIGHTS_EPOCH, w._version, w.data_ptr())
+        if stamp == now or stamp[2] != now[2] or wt.shape != (w.shape[1], w.shape[0]):
+            continue
+        by_shape.setdefault((w.shape[0], w.shape[1], w.device), []).append((key, w, wt, ref, now))
+    for (R, C, dev), items in by_shape.items():
+        if R % 8 or C % 8:
+            continue
+        ptrs = tuple((w.data_ptr(), wt.data_ptr()) for _, w, wt, _, _ in items)
+        tab = _PTR_TABLES.get(ptrs)
+        if tab is None:
+            if len(_PTR_TABLES) > 64:
+                _PTR_TABLES.clear()
+            tab = _PTR_TABLES[ptrs] = (torch.tensor([a for a, _ in ptrs], dtype=torch.int64, device=dev),
+                                       torch.tensor([b for _, b in ptrs], dtype=torch.int64, device=dev))
+        ops().transpose_bf16_many(tab[0], tab[1], R, C)
+        for key, w, wt, ref, now in items:
+            _WT_CACHE[key] = (now, wt, ref)
 
 
 def transposed_weight(w: torch.Tensor) -> torch.Tensor:
@@ -133,6 +168,12 @@ def transposed_weight(w: torch.Tensor) -> torch.Tensor:
     ent = _WT_CACHE.get(key)
     if ent is not None and ent[0] == stamp and ent[2]() is w:
         return ent[1]
+    if ent is not None and ent[2]() is w and getattr(w, "_dpa_resident", False) and _BATCH_TRANSPOSES:
+        # the first stale request after an optimizer step refreshes every resident weight's transpose
+        _refresh_resident_transposes()
+        ent = _WT_CACHE.get(key)
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
     wt = ops().transpose_bf16(w.detach())
     if len(_WT_CACHE) > 4096:
         _WT_CACHE.clear()

@@ -55,6 +55,8 @@ class Slot:
 class FlatGroup:
     """One contiguous group of parameters (a bucket / FSDP unit)."""
 
+    resident = True   # the parameters stay at their addresses for the whole run (sharded units: released and re-gathered)
+
     def __init__(self, named_params: Sequence[tuple[str, nn.Parameter]], dtype: torch.dtype, device,
                  pad_multiple: int = 8, weight_decay: float = 0.0, name: str = "", grad_dtype: torch.dtype | None = None):
         self.name = name
@@ -85,6 +87,7 @@ class FlatGroup:
                 view = self.data[s.offset:s.offset + s.numel].view(s.shape)
                 view.copy_(src)
                 s.param.data = view
+                s.param._dpa_resident = self.resident
         self.attach_grads()
 
     # -- gradient buffer --------------------------------------------------------------------

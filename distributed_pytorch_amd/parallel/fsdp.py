@@ -50,6 +50,8 @@ def _debug_streams() -> bool:
 class FSDPUnit(FlatGroup):
     """A FlatGroup whose full parameter / gradient buffers exist only while needed."""
 
+    resident = False
+
     def __init__(self, named_params, dtype, device, world, rank, weight_decay, name, grad_dtype=None):
         self._defer_grad = True
         super().__init__(named_params, dtype, device, 8 * world, weight_decay, name, grad_dtype=grad_dtype)

@@ -1502,3 +1502,32 @@ def test_grouped_experts_with_dropout_matches_eager(act, U):
                              p_drop=0.5)
     o0 = ops.grouped_experts(x.detach(), idx, gates.detach(), [w.detach() for w in fcs], [w.detach() for w in projs], act)
     assert not torch.equal(o1, o0) and abs(o1.float().mean().item() - o0.float().mean().item()) < 0.05 * o0.float().abs().mean().item() + 1e-3
+
+
+@pytest.mark.gpu
+def test_transposes_of_resident_weights_refresh_in_one_launch_per_shape():
+    """After an optimizer step (the epoch bump) the first stale request refreshes the cached transposes of every
+    weight marked resident: same buffers, new contents; weights not marked resident keep the one-by-one path."""
+    import importlib
+    L = importlib.import_module("distributed_pytorch_amd.ops.linear")   # (the package exports a function of that name)
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(256, 128, device="cuda", dtype=torch.bfloat16)) for _ in range(3)]
+    ws += [torch.nn.Parameter(torch.randn(64, 512, device="cuda", dtype=torch.bfloat16)) for _ in range(2)]
+    other = torch.nn.Parameter(torch.randn(256, 128, device="cuda", dtype=torch.bfloat16))
+    for w in ws:
+        w._dpa_resident = True
+    first = [L.transposed_weight(w) for w in ws + [other]]
+    for w, t in zip(ws + [other], first):
+        assert torch.equal(t, w.detach().t().contiguous())
+    with torch.no_grad():
+        for w in ws + [other]:
+            w.data.view(-1)[:].mul_(-0.5)          # an update that autograd's version counter may or may not see
+    L.bump_weights_epoch()
+    t0 = L.transposed_weight(ws[0])                # refreshes all five resident entries
+    for w, old in zip(ws, first):
+        ent = L._WT_CACHE[id(w)]
+        assert ent[0][0] == L._WEIGHTS_EPOCH and ent[1].data_ptr() == old.data_ptr()
+        assert torch.equal(ent[1], w.detach().t().contiguous())
+    assert t0.data_ptr() == first[0].data_ptr()
+    assert L._WT_CACHE[id(other)][0][0] != L._WEIGHTS_EPOCH      # not resident: still stale until asked for
+    assert torch.equal(L.transposed_weight(other), other.detach().t().contiguous())
