@@ -121,10 +121,64 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // Eight consecutive elements held in their storage format: bf16 stays packed (4 registers per
 // vector), so values that must live across a reduction cost half the registers of fp32.
+// Streaming variants (NT = true: non-temporal cache policy) for tensors that pass through a kernel once and are too
+// large to be found in a cache by their next reader: measured 5.35 -> 5.9 TB/s on the cross-entropy rows.
+template <bool NT>
+__device__ __forceinline__ void load8s(const bf16_t* p, float (&o)[8]) {
+  const u32x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = lo_bf16(v[i]);
+    o[2 * i + 1] = hi_bf16(v[i]);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load8s(const float* p, float (&o)[8]) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(p);
+  const f32x4 a = NT ? __builtin_nontemporal_load(q) : q[0], b = NT ? __builtin_nontemporal_load(q + 1) : q[1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[i] = a[i];
+    o[4 + i] = b[i];
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void store8s(bf16_t* p, const float (&o)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  else *reinterpret_cast<u32x4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store8s(float* p, const float (&o)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = o[i];
+    b[i] = o[4 + i];
+  }
+  f32x4* q = reinterpret_cast<f32x4*>(p);
+  if (NT) {
+    __builtin_nontemporal_store(a, q);
+    __builtin_nontemporal_store(b, q + 1);
+  } else {
+    q[0] = a;
+    q[1] = b;
+  }
+}
+// Tensors of at least this many bytes are streamed (the 256 MiB memory-side cache holds nothing of them by the time
+// their reader comes).
+inline long long stream_threshold_bytes() { return 256ll << 20; }
+
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
   u32x4 v;
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  template <bool NT>
+  __device__ __forceinline__ void loads(const bf16_t* p) {
+    v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
+  }
   // Makes the packed value opaque to the optimizer at this point, so an unpack that follows inside a
   // loop is not hoisted out of it (which would bring the fp32 copy back into live registers).
   __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v)); }
@@ -139,6 +193,8 @@ template <> struct Vec8<bf16_t> {
 template <> struct Vec8<float> {
   float f[8];
   __device__ __forceinline__ void load(const float* p) { load8(p, f); }
+  template <bool NT>
+  __device__ __forceinline__ void loads(const float* p) { load8s<NT>(p, f); }
   __device__ __forceinline__ void pin() {}
   __device__ __forceinline__ void get(float (&o)[8]) const {
 #pragma unroll

@@ -7,6 +7,8 @@
 //
 // Replaces the implicit `nn.LayerNorm` kernels of the reference model
 // (reference: single-gpu/model.py:514-515,557).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -22,7 +24,7 @@ __device__ __forceinline__ float row_sum(float v) {
 
 // LPR lanes own one row (LPR = 32: two rows per wave, used when the row has an odd multiple of
 // 32 sixteen-byte chunks, e.g. C = 768 -> 96 chunks = 3 per lane with no idle lanes).
-template <typename T, int NCH, int LPR>
+template <typename T, int NCH, int LPR, bool NT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                      const T* __restrict__ w, const T* __restrict__ b,
                                                      T* __restrict__ y, T* __restrict__ sum_out,
@@ -40,15 +42,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * LPR;
     if (c < nchunk) {
-      load8(xr + c * 8, v[i]);
+      load8s<NT>(xr + c * 8, v[i]);
       if (res != nullptr) {
         float r[8];
-        load8(res + (size_t)row * C + c * 8, r);
+        load8s<NT>(res + (size_t)row * C + c * 8, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] += r[j];
         if (sum_out != nullptr) {
           // Round through the storage dtype so the statistics see what later kernels will read.
-          store8(sum_out + (size_t)row * C + c * 8, v[i]);
+          store8s<NT>(sum_out + (size_t)row * C + c * 8, v[i]);
         }
       }
 #pragma unroll
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       load8(b + c * 8, bv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
-      store8(y + (size_t)row * C + c * 8, o);
+      store8s<NT>(y + (size_t)row * C + c * 8, o);
     }
   }
 }
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Backward. Each wave walks rows with a grid stride and keeps its dgamma/dbeta partial sums in
 // registers; the four waves of a block are combined through LDS and written as one partial
 // row per block. A second kernel folds the partial rows.
-template <typename T, int NCH, int LPR>
+template <typename T, int NCH, int LPR, bool NT>
 __global__ __launch_bounds__(256, (NCH * (int)sizeof(T) <= 6) ? 3 : 1) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, (NCH * (int)sizeof(T) <= 6) ? 3 : 1) void ln_b
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = lane + i * LPR;
-        if (c < nchunk) rv[i].load(dres + (size_t)row * C + c * 8);
+        if (c < nchunk) rv[i].template loads<NT>(dres + (size_t)row * C + c * 8);
       }
     }
 #pragma unroll
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256, (NCH * (int)sizeof(T) <= 6) ? 3 : 1) void ln_b
       const int c = lane + i * LPR;
       if (c < nchunk) {
         float d[8], xv[8], wf[8];
-        load8(dy + (size_t)row * C + c * 8, d);
-        load8(x + (size_t)row * C + c * 8, xv);
+        load8s<NT>(dy + (size_t)row * C + c * 8, d);
+        load8s<NT>(x + (size_t)row * C + c * 8, xv);
         wv[i].pin();
         wv[i].get(wf);
 #pragma unroll
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, (NCH * (int)sizeof(T) <= 6) ? 3 : 1) void ln_b
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += r[j];
         }
-        store8(dx + (size_t)row * C + c * 8, o);
+        store8s<NT>(dx + (size_t)row * C + c * 8, o);
       }
     }
   }
@@ -243,6 +245,16 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   }
 }
 
+// Activations of at least this many bytes go through the kernels with the streaming cache policy (benchmark knob:
+// DPA_LN_STREAM_MB).
+static long long ln_stream_bytes() {
+  static const long long v = [] {
+    const char* e = getenv("DPA_LN_STREAM_MB");
+    return e ? (long long)atoll(e) << 20 : stream_threshold_bytes();
+  }();
+  return v;
+}
+
 // Lanes per row and chunks per lane for a row of C elements (C % 8 == 0).
 static void pick_shape(int C, int& lpr, int& nch) {
   const int nchunk = C / 8;
@@ -263,8 +275,12 @@ static void ln_fwd_launch(const T* x, const T* res, const T* w, const T* b, T* y
   pick_shape(C, lpr, nch);
   const int rpb = 4 * (64 / lpr);
   const dim3 grid((rows + rpb - 1) / rpb), block(256);
-#define DPA_CASE(N, L)                                                                                     \
-  hipLaunchKernelGGL((ln_fwd_kernel<T, N, L>), grid, block, 0, st, x, res, w, b, y, sum_out, mean, rstd, rows, C, eps)
+  const bool nt = (long long)rows * C * (long long)sizeof(T) >= ln_stream_bytes();
+#define DPA_CASE(N, L)                                                                                              \
+  do {                                                                                                              \
+    if (nt) hipLaunchKernelGGL((ln_fwd_kernel<T, N, L, true>), grid, block, 0, st, x, res, w, b, y, sum_out, mean, rstd, rows, C, eps); \
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, N, L, false>), grid, block, 0, st, x, res, w, b, y, sum_out, mean, rstd, rows, C, eps);   \
+  } while (0)
   if (lpr == 32) {
     switch (nch) {
       case 1: DPA_CASE(1, 32); break;
@@ -296,8 +312,12 @@ static void ln_bwd_launch(const T* dy, const T* x, const T* w, const float* mean
   const size_t lds = (size_t)2 * 4 * (64 / lpr) * C * sizeof(float);
   float* pw = scratch;
   float* pb = scratch + (size_t)nparts * C;
-#define DPA_CASE(N, L)                                                                                        \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, N, L>), grid, block, lds, st, dy, x, w, mean, rstd, dres, dx, pw, pb, rows, C)
+  const bool nt = (long long)rows * C * (long long)sizeof(T) >= ln_stream_bytes();
+#define DPA_CASE(N, L)                                                                                                 \
+  do {                                                                                                                 \
+    if (nt) hipLaunchKernelGGL((ln_bwd_kernel<T, N, L, true>), grid, block, lds, st, dy, x, w, mean, rstd, dres, dx, pw, pb, rows, C); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, N, L, false>), grid, block, lds, st, dy, x, w, mean, rstd, dres, dx, pw, pb, rows, C);   \
+  } while (0)
   if (lpr == 32) {
     switch (nch) {
       case 1: DPA_CASE(1, 32); break;

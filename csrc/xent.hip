@@ -25,6 +25,22 @@ constexpr int kXentMaxVec = 8;  // vectors of 8 logits cached per thread -> V <=
 
 __device__ __forceinline__ float exp_diff(float d) { return d != d ? 0.f : __expf(d); }  // (-inf) - (-inf) -> 0
 
+// The per-element work is counted in instructions: at the HBM rate a CU has about 25 vector instructions per element
+// (read + write) to spend and the three passes over a row used 18 of them. exp(x - r) is one fused multiply-add and
+// one v_exp_f32 (r pre-multiplied by log2(e)); the one-hot subtraction is a single store by the thread that owns
+// the target's vector, after the row's gradient has been written, instead of a compare and a select per element.
+#ifndef DPA_XENT_NT
+#define DPA_XENT_NT 3   // bit 0 loads, bit 1 stores: the row is read once and written once: non-temporal accesses (nothing here is reused from a cache)
+#endif
+template <typename T>
+__device__ __forceinline__ void row_load(Vec8<T>& c, const T* p) { c.template loads<(DPA_XENT_NT & 1) != 0>(p); }
+template <typename T>
+__device__ __forceinline__ void row_store(T* p, const float (&o)[8]) { store8s<(DPA_XENT_NT & 2) != 0>(p, o); }
+constexpr float kL2e = 1.4426950408889634f;
+__device__ __forceinline__ float exp2_scaled(float x, float neg_ref_l2e) {
+  return __builtin_amdgcn_exp2f(fmaf(x, kL2e, neg_ref_l2e));
+}
+
 // Block-wide log-sum-exp combine of per-thread (max, sum of exp(x - max)) pairs: one LDS round.
 __device__ __forceinline__ void block_lse(float& m, float& s, float* red /* 32 floats */) {
 #pragma unroll
@@ -84,13 +100,14 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
       for (int k = 0; k < kXentMaxVec; ++k) {
         const int i = threadIdx.x + k * kXentThreads;
         if (i < nvec) {
-          cache[k].load(lr + i * 8);
+          row_load(cache[k], lr + i * 8);
           float x[8];
           cache[k].get(x);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) mx = fmaxf(mx, x[j]);
+          for (int j = 0; j < 8; j += 2) mx = fmaxf(fmaxf(mx, x[j]), x[j + 1]);   // v_max3_f32
         }
       }
+      const float nm = -mx * kL2e;
 #pragma unroll
       for (int k = 0; k < kXentMaxVec; ++k) {
         const int i = threadIdx.x + k * kXentThreads;
@@ -98,7 +115,7 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
           float x[8];
           cache[k].get(x);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) sum += __expf(x[j] - mx);
+          for (int j = 0; j < 8; ++j) sum += exp2_scaled(x[j], nm);
         }
       }
       block_lse(mx, sum, red);
@@ -110,11 +127,12 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
         for (int j = 0; j < 8; ++j) mx = fmaxf(mx, x[j]);
       }
       mx = block_max(mx, red);
+      const float nm = -mx * kL2e;
       for (int i = threadIdx.x; i < nvec; i += kXentThreads) {
         float x[8];
         load8(lr + i * 8, x);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += __expf(x[j] - mx);
+        for (int j = 0; j < 8; ++j) sum += exp2_scaled(x[j], nm);
       }
       sum = block_sum(sum, red);
     }
@@ -141,6 +159,13 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
 
   if (!write_grad) return;
   const float scale = ignored ? 0.f : *grad_scale;
+  const float nl = -lse * kL2e;
+  // The target's element: its vector's owner reads the logit now and stores (p - 1) * scale over what the row
+  // pass writes there (a thread's stores to one address land in program order).
+  const bool tgt_here = !ignored && tloc >= 0 && tloc < V;
+  const bool owner = tgt_here && (int)threadIdx.x == ((tloc >> 3) & (kXentThreads - 1));
+  float xt = 0.f;
+  if (owner) xt = Cvt<T>::ld(lr + tloc);
   __syncthreads();  // every thread has read its logits before anybody overwrites (target read above)
   if (CACHED && MODE == XENT_FUSED) {
 #pragma unroll
@@ -150,11 +175,8 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
         float x[8], o[8];
         cache[k].get(x);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float p = __expf(x[j] - lse);
-          o[j] = (p - ((i * 8 + j) == tloc ? 1.f : 0.f)) * scale;
-        }
-        store8(lr + i * 8, o);
+        for (int j = 0; j < 8; ++j) o[j] = exp2_scaled(x[j], nl) * scale;
+        row_store(lr + i * 8, o);
       }
     }
   } else {
@@ -162,12 +184,13 @@ __global__ __launch_bounds__(kXentThreads, sizeof(T) == 2 ? 8 : 4) void xent_ker
       float x[8], o[8];
       load8(lr + i * 8, x);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float p = __expf(x[j] - lse);
-        o[j] = (p - ((i * 8 + j) == tloc ? 1.f : 0.f)) * scale;
-      }
+      for (int j = 0; j < 8; ++j) o[j] = exp2_scaled(x[j], nl) * scale;
       store8(lr + i * 8, o);
     }
+  }
+  if (owner) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row pass's store of this element has been taken
+    Cvt<T>::st(lr + tloc, (exp2_scaled(xt, nl) - 1.f) * scale);
   }
 }
 
