@@ -365,6 +365,16 @@ int main(int argc, char** argv) {
     }
     dpa::gemm_nt_set_variant(0);
   }
+  if (!strcmp(mode, "aux")) {   // the multiply / add epilogues (auxiliary operand read in the epilogue), 2 us start skew
+    const int M = argc > 2 ? atoi(argv[2]) : 65536;
+    dpa::gemm_nt_set_variant(200 << 8);
+    for (int rep = 0; rep < 2; ++rep) {
+      run_case(M, 3072, 768, 2, false, false, 30);
+      run_case(M, 768, 768, 3, true, false, 30);
+      run_case(M, 768, 3072, 3, false, false, 30);
+    }
+    dpa::gemm_nt_set_variant(0);
+  }
   if (!strcmp(mode, "skew")) {
     const int M = 65536;
     for (int ticks : {0, 200, 400, 600, 800}) {   // 100 MHz ticks per group step: 0 .. 8 us

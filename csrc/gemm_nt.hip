@@ -43,6 +43,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 #ifndef DPA_GEMM_STORE_AUX
 #define DPA_GEMM_STORE_AUX 2   // non-temporal: measured 4-6 % faster than the default policy on the K = 768 shapes
 #endif
+#ifndef DPA_GEMM_AUX_LOAD
+#define DPA_GEMM_AUX_LOAD 2   // cache policy of the epilogue loads of the auxiliary operand (read once): non-temporal, -2 % on the dGELU form, neutral on the residual form
+#endif
 #ifndef DPA_GEMM_PREFETCH_A
 #define DPA_GEMM_PREFETCH_A 1   // phase 3 (no fragment reads of its own) reads half of the next K-tile's first A fragments
 #endif
@@ -697,8 +700,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
             const int r1 = cur_m0 + 128 * wr + 64 * mh + 16 * mt + trow, r2 = r1 + 8;
             const unsigned o1 = (cok && r1 < p.M) ? (unsigned)r1 * (unsigned)p.ld_aux * 2u + cb : 0x80000000u;
             const unsigned o2 = (cok && r2 < p.M) ? (unsigned)r2 * (unsigned)p.ld_aux * 2u + cb : 0x80000000u;
-            ax[mh][mt][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o1, 0, 0);
-            ax[mh][mt][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o2, 0, 0);
+            ax[mh][mt][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o1, 0, DPA_GEMM_AUX_LOAD);
+            ax[mh][mt][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, o2, 0, DPA_GEMM_AUX_LOAD);
           }
       }
       // Rotary form: the lane's 16 columns are 8 (even, odd) pairs of one head (heads are 64 or 128 wide and
