@@ -533,13 +533,40 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
                                                            long long nvec, int nslabs, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * blockDim.x) {
+    // Eight slabs are requested together: a small weight has fewer vectors than the chip has threads and up to 64
+    // slabs, and one load per round trip made the fold a chain of memory latencies (19 us for 65 MB).
     float a[8];
     load8(ws + i * 8, a);
-    for (int s = 1; s < nslabs; ++s) {
-      float b[8];
-      load8(ws + (long long)s * nvec * 8 + i * 8, b);
+    int s = 1;
+    for (; s + 8 <= nslabs; s += 8) {
+      float b[8][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] += b[j];
+      for (int u = 0; u < 8; ++u) load8(ws + (long long)(s + u) * nvec * 8 + i * 8, b[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[u][j];
+    }
+    if (s + 4 <= nslabs) {
+      float b[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load8(ws + (long long)(s + u) * nvec * 8 + i * 8, b[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[u][j];
+      s += 4;
+    }
+    {
+      float b[3][8];   // the last 0-3 slabs, requested together as well
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (s + u < nslabs) load8(ws + (long long)(s + u) * nvec * 8 + i * 8, b[u]);
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (s + u < nslabs)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += b[u][j];
     }
     if (accumulate) {
       float o[8];
