@@ -118,7 +118,19 @@ __global__ __launch_bounds__(128) void embed_bwd_fix_kernel(const long long* __r
   for (int cv = threadIdx.x; cv < nvec; cv += blockDim.x) {
     float acc[8];
     load8(tail + (size_t)blockIdx.x * C + cv * 8, acc);
-    for (long long j = blockIdx.x + 1; j <= last_chunk; ++j) {
+    // (eight partial rows per round trip: the run of a frequent token spans hundreds of chunks, and one load per
+    // round trip made this fold a 300 us chain of memory latencies in a single workgroup)
+    long long j = blockIdx.x + 1;
+    for (; j + 8 <= last_chunk + 1; j += 8) {
+      float h[8][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) load8(head + (size_t)(j + u) * C + cv * 8, h[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += h[u][k];
+    }
+    for (; j <= last_chunk; ++j) {
       float h[8];
       load8(head + (size_t)j * C + cv * 8, h);
 #pragma unroll
@@ -143,7 +155,17 @@ __global__ __launch_bounds__(256) void pos_bwd_kernel(const T* __restrict__ dout
     const int c = (int)(i - (long long)t * nvec) * 8;
     float acc[8];
     load8(dpos + (size_t)(pos0 + t) * C + c, acc);
-    for (int b = 0; b < B; ++b) {
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {   // eight batch rows per round trip (T * C / 8 threads do not fill the chip)
+      float d[8][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) load8(dout + ((size_t)(b + u) * T_len + t) * C + c, d[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += d[u][k];
+    }
+    for (; b < B; ++b) {
       float d[8];
       load8(dout + ((size_t)b * T_len + t) * C + c, d);
 #pragma unroll
