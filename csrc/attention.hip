@@ -36,6 +36,10 @@
 
 namespace dpa {
 
+#ifndef DPA_ATTN_NT_STORE
+#define DPA_ATTN_NT_STORE 0   // output tiles (O, dQ, dK, dV) stored with the non-temporal policy: measured, no change in the step
+#endif
+
 // A wave's [32][HS] output tile, held transposed (rows = d on registers, column = lane), is
 // turned into whole rows through LDS and stored with 16-byte accesses. The 16-byte chunks of a row are
 // XOR-swizzled with the row index: without it the 32 lanes of a half-wave write one bank column (row
@@ -76,7 +80,11 @@ __device__ __forceinline__ void store_tile_T(char* wave_lds, const f32x16 (&acc)
         v[j] = pack_bf16x2(re * c[j] + im * sn[j], im * c[j] - re * sn[j]);
       }
     }
-    if (row0 + row < nrows) *reinterpret_cast<u32x4*>(out + (long long)(row0 + row) * ts + ch * 8) = v;
+    if (row0 + row < nrows) {
+      u32x4* dst = reinterpret_cast<u32x4*>(out + (long long)(row0 + row) * ts + ch * 8);
+      if (DPA_ATTN_NT_STORE) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
+    }
   }
 }
 

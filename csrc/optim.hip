@@ -14,6 +14,11 @@
 
 namespace dpa {
 
+#ifndef DPA_OPT_NT
+#define DPA_OPT_NT 0   // non-temporal accesses of the state and the weights: measured, no change (173 us either way)
+#endif
+constexpr bool kOptNt = DPA_OPT_NT != 0;
+
 template <typename GT, typename PT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m,
                                                     float* __restrict__ v, const GT* __restrict__ grad,
@@ -52,10 +57,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
       }
     }
     float p[8], mm[8], vv[8], g[8];
-    load8(master + e, p);
-    load8(m + e, mm);
-    load8(v + e, vv);
-    load8(grad + e, g);
+    load8s<kOptNt>(master + e, p);
+    load8s<kOptNt>(m + e, mm);
+    load8s<kOptNt>(v + e, vv);
+    load8s<kOptNt>(grad + e, g);
     const float decay = 1.f - lr * wd;
     const float step = lr / bc1;
 #pragma unroll
@@ -66,10 +71,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
       const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
       p[j] = p[j] * decay - step * (mm[j] / denom);
     }
-    store8(master + e, p);
-    store8(m + e, mm);
-    store8(v + e, vv);
-    if (param_out != nullptr) store8(param_out + e, p);
+    store8s<kOptNt>(master + e, p);
+    store8s<kOptNt>(m + e, mm);
+    store8s<kOptNt>(v + e, vv);
+    if (param_out != nullptr) store8s<kOptNt>(param_out + e, p);
   }
 }
 
