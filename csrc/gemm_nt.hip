@@ -788,15 +788,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
             u32x4 o, hg, hu;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float a2[2];
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const float g = v[2 * j + e];
-                a2[e] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g)) * v[8 + 2 * j + e];
-              }
+              // silu(g) * u on a pair of columns in packed fp32 arithmetic
+              const f32x2 g = {v[2 * j], v[2 * j + 1]}, u = {v[8 + 2 * j], v[8 + 2 * j + 1]};
+              const f32x2 z = g * splat2(-1.4426950408889634f);
+              const f32x2 den = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + splat2(1.0f);
+              const f32x2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+              const f32x2 a2 = g * sg * u;
               o[j] = pack_bf16x2(a2[0], a2[1]);
-              hg[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-              hu[j] = pack_bf16x2(v[8 + 2 * j], v[8 + 2 * j + 1]);
+              hg[j] = pack_bf16x2(g[0], g[1]);
+              hu[j] = pack_bf16x2(u[0], u[1]);
             }
             const unsigned oc = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)colq) * 2u : 0x80000000u;
             const unsigned og = ok ? ((unsigned)row * (unsigned)p.ld_aux + (unsigned)colq) * 2u : 0x80000000u;
@@ -814,20 +814,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNtArgs p) {
             u32x4 dg0, dg1, du0, du1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float dgv[4], duv[4];
-              const float gs[4] = {lo_bf16(g0[j]), hi_bf16(g0[j]), lo_bf16(g1[j]), hi_bf16(g1[j])};
-              const float us[4] = {lo_bf16(u0[j]), hi_bf16(u0[j]), lo_bf16(u1[j]), hi_bf16(u1[j])};
-              const float ds[4] = {v[2 * j], v[2 * j + 1], v[8 + 2 * j], v[8 + 2 * j + 1]};
+              // pairs in packed fp32 arithmetic: d(up) = ds g sg, d(gate) = ds u sg (1 + g (1 - sg)), sg = sigmoid(g)
+              const f32x2 gs[2] = {{lo_bf16(g0[j]), hi_bf16(g0[j])}, {lo_bf16(g1[j]), hi_bf16(g1[j])}};
+              const f32x2 us[2] = {{lo_bf16(u0[j]), hi_bf16(u0[j])}, {lo_bf16(u1[j]), hi_bf16(u1[j])}};
+              const f32x2 ds[2] = {{v[2 * j], v[2 * j + 1]}, {v[8 + 2 * j], v[8 + 2 * j + 1]}};
+              f32x2 dgv[2], duv[2];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gs[e]));
-                duv[e] = ds[e] * gs[e] * sg;
-                dgv[e] = ds[e] * us[e] * sg * (1.0f + gs[e] * (1.0f - sg));
+              for (int e = 0; e < 2; ++e) {
+                const f32x2 z = gs[e] * splat2(-1.4426950408889634f);
+                const f32x2 den = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + splat2(1.0f);
+                const f32x2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                const f32x2 dsg = ds[e] * sg;
+                duv[e] = dsg * gs[e];
+                const f32x2 w = pk_fma(gs[e], splat2(1.0f) - sg, splat2(1.0f));   // 1 + g (1 - sg)
+                dgv[e] = dsg * us[e] * w;
               }
-              dg0[j] = pack_bf16x2(dgv[0], dgv[1]);
-              dg1[j] = pack_bf16x2(dgv[2], dgv[3]);
-              du0[j] = pack_bf16x2(duv[0], duv[1]);
-              du1[j] = pack_bf16x2(duv[2], duv[3]);
+              dg0[j] = pack_bf16x2(dgv[0][0], dgv[0][1]);
+              dg1[j] = pack_bf16x2(dgv[1][0], dgv[1][1]);
+              du0[j] = pack_bf16x2(duv[0][0], duv[0][1]);
+              du1[j] = pack_bf16x2(duv[1][0], duv[1][1]);
             }
             store_rows16(rsC, dg0, dg1, row0, col0, lim, (unsigned)p.ldc);
             store_rows16(rsC, du0, du1, row0, col0 + p.N, lim, (unsigned)p.ldc);
