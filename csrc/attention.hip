@@ -186,6 +186,18 @@ __device__ __forceinline__ void dma_piece(unsigned lds_addr, unsigned voff, rsrc
 }
 
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_dma_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// K/V stages of the forward. Three (a tile requested two tiles ahead, 48 KiB per workgroup at head size 64) were
+// measured 25 % SLOWER than two (186 -> 234 us at B64 T1024 nh12): the wait for a tile requested one tile ahead was
+// short already, and the third stage costs the third workgroup per CU. Kept as a build knob.
+#ifndef DPA_ATTN_FWD_STAGES
+#define DPA_ATTN_FWD_STAGES 2
+#endif
+__host__ __device__ constexpr int fwd_stages(int dk, int dv) {
+  return (DPA_ATTN_FWD_STAGES == 3 && 64 * dk * 2 + 64 * dv * 2 <= 16384) ? 3 : 2;
+}
 
 template <int HS>
 struct TileDma {
@@ -274,6 +286,7 @@ __device__ __forceinline__ float fwd_exp2(float x) { return DPA_ATTN_ABLATE ? x 
 template <int DK, int DV, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int NK = DK / 16, ND = DV / 32, KTILE = 64 * DK * 2, VTILE = 64 * DV * 2, STAGE = KTILE + VTILE;
+  constexpr int NST = fwd_stages(DK, DV);   // K/V tiles in LDS: the transfer of tile t + NST - 1 is issued during tile t
   constexpr int KCH = NK > 8 ? 8 : NK;   // K fragments requested together (wide keys: in two or more batches)
   constexpr int KSUB = 2;   // head size 64: 32-key sub-tiles whose fragments are in registers together
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -317,6 +330,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     if (qrow < p.Tq) qf[ks] = scaled_frag(qp + (long long)qrow * p.q_ts + ks * 16 + hh * 8, c);
   }
 
+  if (NST == 3 && ntiles > 1) {   // (after the Q loads: the first tile's wait leaves exactly this tile's pieces in flight)
+    kd.issue(krs, 64, Tk, lds0 + STAGE);
+    vd.issue(vrs, 64, Tk, lds0 + STAGE + KTILE);
+  }
+
   f32x16 oacc[ND], negm;
 #pragma unroll
   for (int i = 0; i < 16; ++i) negm[i] = 0.f;
@@ -334,18 +352,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const bool tracing = blockIdx.x == 300 && DK == 64;   // a workgroup of the first batch with all 16 tiles
   if (tracing) for (int i = tid; i < 4 * 16 * 7; i += 256) (&trace_s[0][0][0])[i] = 0u;
 #endif
+  int st_cur = 0;   // t % NST
   for (int t = 0; t < ntiles; ++t) {
     DPA_ATR(0);
-    wait_dma();
+    // three stages: tile t was requested two tiles ago and only tile t + 1's pieces may still be in flight
+    if (NST == 3 && t + 1 < ntiles) wait_dma_but<TileDma<DK>::NP + TileDma<DV>::NP>();
+    else wait_dma();
     __syncthreads();   // tile t has landed for every wave; every wave is done with tile t - 1's buffer
     DPA_ATR(1);
-    if (t + 1 < ntiles) {
-      const unsigned nb = lds0 + ((t + 1) & 1) * STAGE;
-      kd.issue(krs, (t + 1) * 64, Tk, nb);
-      vd.issue(vrs, (t + 1) * 64, Tk, nb + KTILE);
+    if (t + NST - 1 < ntiles) {
+      int sn = st_cur + NST - 1;
+      if (sn >= NST) sn -= NST;
+      const unsigned nb = lds0 + sn * STAGE;
+      kd.issue(krs, (t + NST - 1) * 64, Tk, nb);
+      vd.issue(vrs, (t + NST - 1) * 64, Tk, nb + KTILE);
     }
     DPA_ATR(2);
-    const char* kb = smem + (t & 1) * STAGE;
+    const char* kb = smem + st_cur * STAGE;
+    st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
     const char* vb = kb + KTILE;
     const int kv0 = t * 64;
     if constexpr (DK == 64 && DV == 64) {
@@ -980,7 +1004,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 template <int DK, int DV, bool DROP>
 static void fwd_launch(const AttnParams& p, hipStream_t st) {
   const int nqt = (p.Tq + 127) / 128;
-  const size_t lds = 2 * (64 * DK * 2 + 64 * DV * 2);
+  const size_t lds = (size_t)fwd_stages(DK, DV) * (64 * DK * 2 + 64 * DV * 2);
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DK, DV, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
