@@ -739,12 +739,35 @@ void check_pairs(const Tensor& row_of_pair) {
               "row_of_pair: int64 cuda");
 }
 
+// A padded expert-sorted buffer [rows, C] whose pair-less rows are zero: with the layout's tables (seg_start, counts,
+// seg_rows: int64 [E]) only those rows are written here, the caller's kernel writes the others; without them the
+// whole buffer is zero-filled.
+static Tensor padded_buffer(int64_t rows, int64_t C, const Tensor& like, const std::optional<Tensor>& seg_start,
+                            const std::optional<Tensor>& counts, const std::optional<Tensor>& seg_rows) {
+  if (!(seg_start.has_value() && counts.has_value() && seg_rows.has_value()))
+    return at::zeros({rows, C}, like.options());
+  const int64_t E = seg_start->numel();
+  TORCH_CHECK(E > 0 && counts->numel() == E && seg_rows->numel() == E && seg_start->is_cuda() && counts->is_cuda() &&
+                  seg_rows->is_cuda() && seg_start->scalar_type() == at::kLong && counts->scalar_type() == at::kLong &&
+                  seg_rows->scalar_type() == at::kLong && seg_start->is_contiguous() && counts->is_contiguous() &&
+                  seg_rows->is_contiguous(),
+              "padded buffer: seg_start / counts / seg_rows are contiguous int64 cuda [E]");
+  Tensor dst = at::empty({rows, C}, like.options());
+  // padding rows per expert are fewer than the layout's block (<= 256); the tail past the last segment fewer than E blocks
+  dpa::moe_zero_padding(dst.data_ptr(), (const long long*)seg_start->data_ptr<int64_t>(),
+                        (const long long*)counts->data_ptr<int64_t>(), (const long long*)seg_rows->data_ptr<int64_t>(), (int)E,
+                        (int)C, rows, 256, cur_stream());
+  return dst;
+}
+
 // dst[row_of_pair[j]] = src[j / k]; other rows zero.
-Tensor moe_scatter_rows(const Tensor& src, const Tensor& row_of_pair, int64_t k, int64_t rows_out) {
+Tensor moe_scatter_rows(const Tensor& src, const Tensor& row_of_pair, int64_t k, int64_t rows_out,
+                        const std::optional<Tensor>& seg_start, const std::optional<Tensor>& counts,
+                        const std::optional<Tensor>& seg_rows) {
   check_rows2d(src, "src");
   check_pairs(row_of_pair);
   TORCH_CHECK(src.is_contiguous() && src.size(1) % 8 == 0 && row_of_pair.numel() == src.size(0) * k);
-  Tensor dst = at::zeros({rows_out, src.size(1)}, src.options());
+  Tensor dst = padded_buffer(rows_out, src.size(1), src, seg_start, counts, seg_rows);
   dpa::moe_scatter_rows(src.data_ptr(), (const long long*)row_of_pair.data_ptr<int64_t>(), dst.data_ptr(),
                         row_of_pair.numel(), (int)k, (int)src.size(1), cur_stream());
   return dst;
@@ -770,7 +793,8 @@ Tensor moe_gather_combine(const Tensor& y, const Tensor& row_of_pair, const std:
 }
 
 std::tuple<Tensor, Tensor> moe_combine_bwd(const Tensor& dout, const Tensor& y, const Tensor& row_of_pair,
-                                           const Tensor& gates) {
+                                           const Tensor& gates, const std::optional<Tensor>& seg_start,
+                                           const std::optional<Tensor>& counts, const std::optional<Tensor>& seg_rows) {
   check_rows2d(dout, "dout");
   check_rows2d(y, "y");
   check_pairs(row_of_pair);
@@ -780,7 +804,7 @@ std::tuple<Tensor, Tensor> moe_combine_bwd(const Tensor& dout, const Tensor& y, 
   TORCH_CHECK(gates.is_cuda() && gates.scalar_type() == at::kBFloat16 && gates.is_contiguous() &&
                   gates.numel() == npairs,
               "gates: bf16 [tokens, k]");
-  Tensor dy = at::zeros_like(y);
+  Tensor dy = padded_buffer(y.size(0), C, y, seg_start, counts, seg_rows);
   Tensor dgate = at::empty({ntok, npairs / ntok}, dout.options().dtype(at::kFloat));
   dpa::moe_combine_bwd(dout.data_ptr(), y.data_ptr(), (const long long*)row_of_pair.data_ptr<int64_t>(),
                        gates.data_ptr(), dy.data_ptr(), dgate.data_ptr<float>(), npairs, (int)(npairs / ntok), (int)C,
@@ -1270,9 +1294,9 @@ TORCH_LIBRARY(dpa, m) {
   m.def("moe_plan(Tensor idx, int n_experts, int rows, int block) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("grouped_gemm(Tensor a, Tensor w_ptrs, int w_rows, int w_cols, bool w_is_kn, Tensor block_group) -> Tensor");
   m.def("grouped_wgrad(Tensor dy, Tensor x, Tensor seg_start, Tensor seg_rows) -> Tensor");
-  m.def("moe_scatter_rows(Tensor src, Tensor row_of_pair, int k, int rows_out) -> Tensor");
+  m.def("moe_scatter_rows(Tensor src, Tensor row_of_pair, int k, int rows_out, Tensor? seg_start=None, Tensor? counts=None, Tensor? seg_rows=None) -> Tensor");
   m.def("moe_gather_combine(Tensor y, Tensor row_of_pair, Tensor? gates, int k) -> Tensor");
-  m.def("moe_combine_bwd(Tensor dout, Tensor y, Tensor row_of_pair, Tensor gates) -> (Tensor, Tensor)");
+  m.def("moe_combine_bwd(Tensor dout, Tensor y, Tensor row_of_pair, Tensor gates, Tensor? seg_start=None, Tensor? counts=None, Tensor? seg_rows=None) -> (Tensor, Tensor)");
   m.def("colsum(Tensor x) -> Tensor");
   m.def("wgrad_into(Tensor dy, Tensor x, Tensor(a!) ws, Tensor(b!)? dbias) -> ()");
   m.def("ws_to(Tensor ws, Tensor(a!) out, bool accumulate) -> ()");

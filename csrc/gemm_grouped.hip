@@ -368,6 +368,37 @@ void moe_scatter_rows(const void* src, const long long* row_of_pair, void* dst, 
                      row_of_pair, (bf16_t*)dst, npairs, k, C);
 }
 
+// Zeroes the rows of a padded expert-sorted buffer that hold no pair: rows [seg_start[e] + counts[e], seg_start[e] +
+// seg_rows[e]) of every expert and everything past the last segment. The buffer's other rows are written by the
+// scatter / combine-backward kernels, so the caller can allocate it uninitialised (the padding is at most
+// experts x (block - 1) rows of a buffer of hundreds of thousands).
+__global__ __launch_bounds__(256) void moe_zero_padding_kernel(bf16_t* __restrict__ dst, const long long* __restrict__ seg_start,
+                                                               const long long* __restrict__ counts,
+                                                               const long long* __restrict__ seg_rows, int E, int C,
+                                                               long long rows_total) {
+  const int e = blockIdx.x;
+  long long r0, r1;
+  if (e < E) {
+    r0 = seg_start[e] + counts[e];
+    r1 = seg_start[e] + seg_rows[e];
+  } else {
+    r0 = seg_start[E - 1] + seg_rows[E - 1];
+    r1 = rows_total;
+  }
+  if (r1 > rows_total) r1 = rows_total;
+  const int nvec = C >> 3;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (long long r = r0 + blockIdx.y; r < r1; r += gridDim.y)
+    for (int c = threadIdx.x; c < nvec; c += 256) *reinterpret_cast<u32x4*>(dst + r * C + c * 8) = z;
+}
+
+void moe_zero_padding(void* dst, const long long* seg_start, const long long* counts, const long long* seg_rows, int E,
+                      int C, long long rows_total, int block, hipStream_t st) {
+  if (E <= 0 || rows_total == 0) return;
+  hipLaunchKernelGGL(moe_zero_padding_kernel, dim3(E + 1, block > 0 ? block : 1), dim3(256), 0, st, (bf16_t*)dst, seg_start,
+                     counts, seg_rows, E, C, rows_total);
+}
+
 void moe_gather_combine(const void* y, const long long* row_of_pair, const void* gates, void* out, long long ntok,
                         int k, int C, hipStream_t st) {
   if (ntok == 0) return;

@@ -250,6 +250,9 @@ void moe_scatter_rows(const void* src, const long long* row_of_pair, void* dst, 
                       hipStream_t st);
 void moe_gather_combine(const void* y, const long long* row_of_pair, const void* gates, void* out, long long ntok,
                         int k, int C, hipStream_t st);
+// zero the pair-less rows of a padded expert-sorted bf16 buffer [rows_total, C] (grid: (E + 1) x block workgroups)
+void moe_zero_padding(void* dst, const long long* seg_start, const long long* counts, const long long* seg_rows, int E,
+                      int C, long long rows_total, int block, hipStream_t st);
 void moe_combine_bwd(const void* dout, const void* y, const long long* row_of_pair, const void* gates, void* dy,
                      float* dgate, long long npairs, int k, int C, hipStream_t st);
 

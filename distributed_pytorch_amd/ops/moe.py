@@ -289,9 +289,10 @@ class _GroupedExpertsFn(torch.autograd.Function):
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         k = topk_indices.shape[1]
-        row_of_pair, block_group, seg_start, seg_rows, rows = (layout or plan(topk_indices, E))[:5]
+        row_of_pair, block_group, seg_start, seg_rows, rows, counts = (layout or plan(topk_indices, E))[:6]
         fc_ptrs, proj_ptrs = _ptr_table(fc), _ptr_table(proj)
-        xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows)
+        # (with the layout's tables only the pair-less rows of the padded buffer are zeroed, not all of it)
+        xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows, seg_start, counts, seg_rows)
         h = ops().grouped_gemm(xs, fc_ptrs, fc[0].shape[0], fc[0].shape[1], False, block_group)
         a = _act_fwd(h, act)
         y = ops().grouped_gemm(a, proj_ptrs, proj[0].shape[0], proj[0].shape[1], False, block_group)
@@ -300,7 +301,7 @@ class _GroupedExpertsFn(torch.autograd.Function):
             y = y * keep            # dropout sits on every expert's output, before the gate (reference: Expert -> MLP)
         gates_c = gates.contiguous()
         out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
-        ctx.save_for_backward(xs, h, y, gates_c, row_of_pair, block_group, seg_start, seg_rows, keep)
+        ctx.save_for_backward(xs, h, y, gates_c, row_of_pair, block_group, seg_start, seg_rows, keep, counts)
         ctx.params = weights
         ctx.act = act
         ctx.k = k
@@ -308,14 +309,14 @@ class _GroupedExpertsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        xs, h, y, gates, row_of_pair, block_group, seg_start, seg_rows, keep = ctx.saved_tensors
+        xs, h, y, gates, row_of_pair, block_group, seg_start, seg_rows, keep, counts = ctx.saved_tensors
         weights = ctx.params
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         # Addresses are looked up again: a sharding engine may have re-materialised the weights.
         fc_ptrs, proj_ptrs = _ptr_table(fc), _ptr_table(proj)
         needs = ctx.needs_input_grad[7:]
-        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates, seg_start, counts, seg_rows)
         if keep is not None:
             dy = dy * keep
         a = _act_fwd(h, ctx.act)
@@ -367,9 +368,9 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         k = topk_indices.shape[1]
-        row_of_pair, block_group, seg_start, seg_rows, rows = (layout or plan(topk_indices, E, NT_BLOCK))[:5]
+        row_of_pair, block_group, seg_start, seg_rows, rows, counts = (layout or plan(topk_indices, E, NT_BLOCK))[:6]
         assert block_group.numel() * NT_BLOCK == rows, "the grouped NT GEMM needs the 256-row layout"
-        xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows)
+        xs = ops().moe_scatter_rows(x_flat, row_of_pair, k, rows, seg_start, counts, seg_rows)
         C = fc[0].shape[1]
         U = proj[0].shape[1]
         # GELU: a = gelu(h), side = gelu'(h); SwiGLU: a = silu(gate) * up, side = [gate | up]
@@ -381,7 +382,7 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
             y = y * keep            # dropout sits on every expert's output, before the gate (reference: Expert -> MLP)
         gates_c = gates.contiguous()
         out = ops().moe_gather_combine(y, row_of_pair, gates_c, k)
-        ctx.save_for_backward(xs, a, side, y, gates_c, row_of_pair, block_group, seg_start, seg_rows, keep)
+        ctx.save_for_backward(xs, a, side, y, gates_c, row_of_pair, block_group, seg_start, seg_rows, keep, counts)
         ctx.params = weights
         ctx.k = k
         ctx.act = act
@@ -390,14 +391,14 @@ class _GroupedExpertsNtFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         from .linear import transposed_weight
-        xs, a, side, y, gates, row_of_pair, block_group, seg_start, seg_rows, keep = ctx.saved_tensors
+        xs, a, side, y, gates, row_of_pair, block_group, seg_start, seg_rows, keep, counts = ctx.saved_tensors
         weights = ctx.params
         E = len(weights) // 2
         fc, proj = weights[:E], weights[E:]
         W, C = fc[0].shape                 # W = U, or 2U with SwiGLU experts
         U = proj[0].shape[1]
         needs = ctx.needs_input_grad[7:]
-        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
+        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates, seg_start, counts, seg_rows)
         if keep is not None:
             dy = dy * keep
         g_proj = [None] * E
