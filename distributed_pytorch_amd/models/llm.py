@@ -643,10 +643,9 @@ class Block(nn.Module):
             attn_out, new_cache = self.attn(h, rope, kv_cache, VAL_RUN, res)
         if fuse_attn:
             x = attn_out   # the updated stream
-            if fuse_mlp:
-                x, h2 = ops.layer_norm_keep(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
-            else:
-                h2 = ops.layer_norm(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+            # (the stream goes on to a second reader either way, the feed-forward GEMM's epilogue or the next block's
+            # add + LayerNorm: its gradient comes back through this LayerNorm's backward kernel instead of a separate add)
+            x, h2 = ops.layer_norm_keep(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
         else:
             x, h2 = ops.add_layer_norm(x, attn_out, self.ln2.weight, self.ln2.bias, self.ln2.eps)
         if self.is_moe:
