@@ -358,19 +358,42 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // slot to land or for a first LDS read. Transfers run three slots ahead (up to 96 KiB in flight).
   constexpr int RSUB = 32 * 128 * 2, RSLOT = 4 * RSUB, NSLOT = DPA_WG3_SLOTS, AHEAD = NSLOT - 1;
   const int nst = 2 * ntiles;      // 32-token stages
-  auto issue_sub = [&](int t, int q) {          // sub-tile q of stage t: dY columns 0 / 128, X columns 0 / 128
-    const unsigned base = lds0 + (t % NSLOT) * RSLOT + q * RSUB;
+  // Transfers: the row block's base address and the LDS destination are scalars, the lane's byte offsets inside a
+  // 32-row block are computed once (rows piece * 4 + lane / 16, swizzled 16-byte chunk lane % 16).
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  unsigned voy[2], vox[2];
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc) {
+    const int row = (wave_s * 2 + pc) * 4 + (lane >> 4);
+    const int chunk = swz<128>(row, lane & 15);
+    voy[pc] = (unsigned)(((long long)row * ldy + chunk * 8) * 2);
+    vox[pc] = (unsigned)(((long long)row * ldx + chunk * 8) * 2);
+  }
+  auto issue_sub = [&](int t, int slot, int q) {   // sub-tile q of stage t into ring slot `slot` (= t % NSLOT)
+    const unsigned base = lds0 + slot * RSLOT + q * RSUB + wave_s * 2048;
     if (t > nst - 1) t = nst - 1;              // past the end: the last stage again (never read), so that the
     const long long m = m_begin + (long long)t * 32;   // count of transfers in flight is the same in every iteration
-    if (q < 2) dma_rows32x128_asm(dy + m * ldy + n0 + ycol1 * q, ldy, 128, base, wave, lane);
-    else dma_rows32x128_asm(x + m * ldx + k0 + 128 * (q - 2), ldx, 128, base, wave, lane);
+    const bf16_t* g = q < 2 ? dy + m * ldy + n0 + ycol1 * q : x + m * ldx + k0 + 128 * (q - 2);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) dma_piece_sbase(g, q < 2 ? voy[pc] : vox[pc], base + pc * 1024);
   };
   auto issue = [&](int t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_sub(t, q);
+    for (int q = 0; q < 4; ++q) issue_sub(t, t % NSLOT, q);
   };
-  auto frag_a = [&](int t, int s, int i) { return tr_frag<128>(smem + (t % NSLOT) * RSLOT + wn * RSUB, 0, s, i, lane); };
-  auto frag_b = [&](int t, int s, int j) { return tr_frag<128>(smem + (t % NSLOT) * RSLOT + (2 + wk) * RSUB, 0, s, j, lane); };
+  // Fragment reads: the lane's LDS addresses of the eight half-fragments of each operand inside slot 0 (k-step 0) are
+  // computed once; a slot's offset is added once per slot (16 additions), the second k-step of a slot is the
+  // instruction's offset field (16 rows x 256 bytes).
+  constexpr int KSTEP = 16 * 128 * 2;
+  unsigned pa[4][2], pb[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const unsigned o = tr_frag_offset<128>(dt, jj, lane);
+      pa[dt][jj] = lds0 + wn * RSUB + o;
+      pb[dt][jj] = lds0 + (2 + wk) * RSUB + o;
+    }
   auto bias_step = [&](const bfrag (&a)[4]) {
     if (BIAS) {
       if (bias_cnt == 0) {
@@ -388,18 +411,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // One token step: the 16 MFMAs on (a, b) in four groups of four; behind group g go the reads of one A and one B
   // fragment of the next step (into an, bn) and, with DMA, the transfer of sub-tile g of stage `tdma`. The
   // sched_group_barrier sequence pins that order (left alone the scheduler sinks every read down to its first use).
-  auto step = [&](const bfrag (&a)[4], const bfrag (&b)[4], bfrag (&an)[4], bfrag (&bn)[4], int tn, int sn, bool dma,
-                  int tdma) {
+  // (fa, fb: the address sets of the slot the NEXT step's fragments come from, imm: 0 or KSTEP)
+  auto step = [&](const bfrag (&a)[4], const bfrag (&b)[4], bfrag (&an)[4], bfrag (&bn)[4], const unsigned (&fa)[4][2],
+                  const unsigned (&fb)[4][2], int imm, bool dma, int tdma, int sdma) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[g][j] = mfma32(a[g], b[j], acc[g][j]);
       // read in the order of first use by the next step: a0 b0 | b1 b2 | b3 a1 | a2 a3
-      if (g == 0) { an[0] = frag_a(tn, sn, 0); bn[0] = frag_b(tn, sn, 0); }
-      if (g == 1) { bn[1] = frag_b(tn, sn, 1); bn[2] = frag_b(tn, sn, 2); }
-      if (g == 2) { bn[3] = frag_b(tn, sn, 3); an[1] = frag_a(tn, sn, 1); }
-      if (g == 3) { an[2] = frag_a(tn, sn, 2); an[3] = frag_a(tn, sn, 3); }
-      if (dma) issue_sub(tdma, g);
+      if (g == 0) { an[0] = tr_frag_at(fa[0], imm); bn[0] = tr_frag_at(fb[0], imm); }
+      if (g == 1) { bn[1] = tr_frag_at(fb[1], imm); bn[2] = tr_frag_at(fb[2], imm); }
+      if (g == 2) { bn[3] = tr_frag_at(fb[3], imm); an[1] = tr_frag_at(fa[1], imm); }
+      if (g == 3) { an[2] = tr_frag_at(fa[2], imm); an[3] = tr_frag_at(fa[3], imm); }
+      if (dma) issue_sub(tdma, sdma, g);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -415,19 +439,46 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     wait_vm<8 * (AHEAD - 1)>();                         // stage 0 (8 transfers per wave and stage, retired in order)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    unsigned xa[4][2], xb[4][2], ya[4][2], yb[4][2];    // address sets of two slots, used in turn
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        xa[dt][jj] = pa[dt][jj];
+        xb[dt][jj] = pb[dt][jj];
+      }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      a0[i] = frag_a(0, 0, i);
-      b0[i] = frag_b(0, 0, i);
+      a0[i] = tr_frag_at(xa[i], 0);
+      b0[i] = tr_frag_at(xb[i], 0);
     }
-    for (int t = 0; t < nst; ++t) {
-      step(a0, b0, a1, b1, t, 1, false, 0);
+    int cur = 0, nxt = 1;   // ring slots of stages t and t + 1 (kept as running indices: no division in the loop)
+    // one stage: `ca, cb` address the slot of stage t, `na, nb` receive the addresses of stage t + 1's slot
+    auto stage = [&](int t, const unsigned (&ca)[4][2], const unsigned (&cb)[4][2], unsigned (&na)[4][2], unsigned (&nb)[4][2]) {
+      step(a0, b0, a1, b1, ca, cb, KSTEP, false, 0, 0);
       // stage t+1 has landed; the barrier also proves that every wave is done reading slot t-1, which stage t+3 overwrites
       wait_vm<8 * (AHEAD - 2)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      step(a1, b1, a0, b0, t + 1, 0, true, t + AHEAD);
+      const unsigned off = (unsigned)nxt * RSLOT;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          na[dt][jj] = pa[dt][jj] + off;
+          nb[dt][jj] = pb[dt][jj] + off;
+        }
+      const int sd = cur == 0 ? NSLOT - 1 : cur - 1;   // (t + AHEAD) % NSLOT with AHEAD = NSLOT - 1
+      step(a1, b1, a0, b0, na, nb, 0, true, t + AHEAD, sd);
+      cur = nxt;
+      nxt = nxt + 1 == NSLOT ? 0 : nxt + 1;
+    };
+    int t = 0;
+    for (; t + 1 < nst; t += 2) {
+      stage(t, xa, xb, ya, yb);
+      stage(t + 1, ya, yb, xa, xb);
     }
+    if (t < nst) stage(t, xa, xb, ya, yb);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transfers past the end
   }
 #else

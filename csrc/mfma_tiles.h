@@ -60,6 +60,32 @@ __device__ __forceinline__ bfrag tr_frag(const char* tile, int rbase, int s, int
   return __builtin_bit_cast(bfrag, v);
 }
 
+// The same fragment from two precomputed LDS byte addresses (the 8-row halves jj = 0, 1 of k-step 0 of a tile) plus a
+// constant: a ring of tiles whose slot changes at run time keeps one such address pair per (operand, dt) in registers,
+// adds the slot's offset once per slot and reaches the tile's second k-step through the instruction's offset field,
+// instead of re-deriving row, swizzle and slot for every read.
+__device__ __forceinline__ bfrag tr_frag_at(const unsigned (&addr)[2], int imm) {
+  s16x4 part[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+    part[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)(addr[jj] + (unsigned)imm));
+  s16x8 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = part[0][j];
+    v[4 + j] = part[1][j];
+  }
+  return __builtin_bit_cast(bfrag, v);
+}
+// LDS byte offset (inside a [rows][HS] tile) of half jj of the fragment that tr_frag(tile, 0, 0, dt, lane) reads.
+template <int HS>
+__device__ __forceinline__ unsigned tr_frag_offset(int dt, int jj, int lane) {
+  const int hh = lane >> 5, g = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int chunk = 4 * dt + 2 * g + (pp >> 1);
+  const int row = 8 * jj + 4 * hh + qq;
+  return (unsigned)(row * (HS * 2) + 16 * swz<HS>(row, chunk) + 8 * (pp & 1));
+}
+
 // Registers 8*s .. 8*s+7 of an accumulator tile -> operand-B fragment of k-step s.
 __device__ __forceinline__ bfrag acc_frag(const f32x16& a, int s) {
   u32x4 v;
@@ -182,6 +208,20 @@ __device__ __forceinline__ void dma_rows32x128_asm(const bf16_t* g, long long ld
         : "=&s"(keep)
         : "v"(src), "s"(dst));
   }
+}
+
+// One 1 KiB piece of such a transfer with the row base in scalar registers: global address = sbase + voff (the lane's
+// byte offset inside the 32-row block, computed once per kernel), LDS address = dst (a scalar). M0 is written and
+// not restored: the kernels that use this touch M0 nowhere else (no other instruction of theirs reads it on gfx950),
+// and the save / restore pair plus the per-lane 64-bit address arithmetic were a third of the ring loop's instructions.
+__device__ __forceinline__ void dma_piece_sbase(const void* sbase, unsigned voff, unsigned dst) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2"
+      :
+      : "v"(voff), "s"(dst), "s"(sbase)
+      : "m0");
 }
 
 }  // namespace dpa
