@@ -361,25 +361,38 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // Transfers: the row block's base address and the LDS destination are scalars, the lane's byte offsets inside a
   // 32-row block are computed once (rows piece * 4 + lane / 16, swizzled 16-byte chunk lane % 16).
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  unsigned voy[2], vox[2];
+  unsigned voff[4][2];   // sub-tile q (dY columns 0 / ycol1, X columns 0 / 128), piece pc
 #pragma unroll
   for (int pc = 0; pc < 2; ++pc) {
     const int row = (wave_s * 2 + pc) * 4 + (lane >> 4);
     const int chunk = swz<128>(row, lane & 15);
-    voy[pc] = (unsigned)(((long long)row * ldy + chunk * 8) * 2);
-    vox[pc] = (unsigned)(((long long)row * ldx + chunk * 8) * 2);
+    const unsigned vy = (unsigned)(((long long)row * ldy + chunk * 8) * 2), vx = (unsigned)(((long long)row * ldx + chunk * 8) * 2);
+    voff[0][pc] = vy;
+    voff[1][pc] = vy + (unsigned)ycol1 * 2u;
+    voff[2][pc] = vx;
+    voff[3][pc] = vx + 256u;
   }
-  auto issue_sub = [&](int t, int slot, int q) {   // sub-tile q of stage t into ring slot `slot` (= t % NSLOT)
+  // row bases of the stage that is transferred next: advanced by 32 rows per stage and held at the last stage (the
+  // transfers past the end re-read it and are never used), so the loop has no 64-bit multiply
+  const bf16_t* gy = dy + (long long)m_begin * ldy + n0;
+  const bf16_t* gx = x + (long long)m_begin * ldx + k0;
+  int t_dma = 0;   // stage the bases point at
+  auto issue_sub = [&](int slot, int q) {   // sub-tile q of stage t_dma into ring slot `slot`
     const unsigned base = lds0 + slot * RSLOT + q * RSUB + wave_s * 2048;
-    if (t > nst - 1) t = nst - 1;              // past the end: the last stage again (never read), so that the
-    const long long m = m_begin + (long long)t * 32;   // count of transfers in flight is the same in every iteration
-    const bf16_t* g = q < 2 ? dy + m * ldy + n0 + ycol1 * q : x + m * ldx + k0 + 128 * (q - 2);
 #pragma unroll
-    for (int pc = 0; pc < 2; ++pc) dma_piece_sbase(g, q < 2 ? voy[pc] : vox[pc], base + pc * 1024);
+    for (int pc = 0; pc < 2; ++pc) dma_piece_sbase(q < 2 ? gy : gx, voff[q][pc], base + pc * 1024);
   };
-  auto issue = [&](int t) {
+  auto next_stage = [&]() {
+    if (t_dma < nst - 1) {
+      gy += 32 * ldy;
+      gx += 32 * ldx;
+    }
+    ++t_dma;
+  };
+  auto issue = [&](int slot) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_sub(t, t % NSLOT, q);
+    for (int q = 0; q < 4; ++q) issue_sub(slot, q);
+    next_stage();
   };
   // Fragment reads: the lane's LDS addresses of the eight half-fragments of each operand inside slot 0 (k-step 0) are
   // computed once; a slot's offset is added once per slot (16 additions), the second k-step of a slot is the
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // sched_group_barrier sequence pins that order (left alone the scheduler sinks every read down to its first use).
   // (fa, fb: the address sets of the slot the NEXT step's fragments come from, imm: 0 or KSTEP)
   auto step = [&](const bfrag (&a)[4], const bfrag (&b)[4], bfrag (&an)[4], bfrag (&bn)[4], const unsigned (&fa)[4][2],
-                  const unsigned (&fb)[4][2], int imm, bool dma, int tdma, int sdma) {
+                  const unsigned (&fb)[4][2], int imm, bool dma, int sdma) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -423,8 +436,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       if (g == 1) { bn[1] = tr_frag_at(fb[1], imm); bn[2] = tr_frag_at(fb[2], imm); }
       if (g == 2) { bn[3] = tr_frag_at(fb[3], imm); an[1] = tr_frag_at(fa[1], imm); }
       if (g == 3) { an[2] = tr_frag_at(fa[2], imm); an[3] = tr_frag_at(fa[3], imm); }
-      if (dma) issue_sub(tdma, sdma, g);
+      if (dma) issue_sub(sdma, g);
     }
+    if (dma) next_stage();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   if (nst > 0) {
     bfrag a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) issue(i);
+    for (int i = 0; i < AHEAD; ++i) issue(i);   // (stages 0 .. AHEAD - 1 into slots of the same numbers)
     wait_vm<8 * (AHEAD - 1)>();                         // stage 0 (8 transfers per wave and stage, retired in order)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     int cur = 0, nxt = 1;   // ring slots of stages t and t + 1 (kept as running indices: no division in the loop)
     // one stage: `ca, cb` address the slot of stage t, `na, nb` receive the addresses of stage t + 1's slot
     auto stage = [&](int t, const unsigned (&ca)[4][2], const unsigned (&cb)[4][2], unsigned (&na)[4][2], unsigned (&nb)[4][2]) {
-      step(a0, b0, a1, b1, ca, cb, KSTEP, false, 0, 0);
+      step(a0, b0, a1, b1, ca, cb, KSTEP, false, 0);
       // stage t+1 has landed; the barrier also proves that every wave is done reading slot t-1, which stage t+3 overwrites
       wait_vm<8 * (AHEAD - 2)>();
       __builtin_amdgcn_s_barrier();
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
           nb[dt][jj] = pb[dt][jj] + off;
         }
       const int sd = cur == 0 ? NSLOT - 1 : cur - 1;   // (t + AHEAD) % NSLOT with AHEAD = NSLOT - 1
-      step(a1, b1, a0, b0, na, nb, 0, true, t + AHEAD, sd);
+      step(a1, b1, a0, b0, na, nb, 0, true, sd);
       cur = nxt;
       nxt = nxt + 1 == NSLOT ? 0 : nxt + 1;
     };
