@@ -160,6 +160,9 @@ __device__ __forceinline__ void tile_order(int bid, int nwg, int ntile, int BH, 
 // per-tile advance is the instruction's scalar offset. Issued from assembly: the compiler would drain
 // an LDS-DMA builtin (vmcnt(0)) before the next LDS read, i.e. right after issuing it.
 // ------------------------------------------------------------------------------------------
+#ifndef DPA_ATTN_LEAN
+#define DPA_ATTN_LEAN 1   // LDS-DMA pieces without the M0 save / restore pair (benchmark knob)
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* ptr) {
@@ -172,7 +175,19 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* ptr) {
   return r;
 }
 
+// (M0 is written and not restored: nothing else in these kernels reads it. Precomputed per-lane fragment addresses, which
+// took 15 % off the one-wave-per-SIMD weight-gradient kernel, were tried on the forward's tile loop too: no change with
+// three waves per SIMD, profiles/r3_attention_lean_loop_experiment.txt)
 __device__ __forceinline__ void dma_piece(unsigned lds_addr, unsigned voff, rsrc_t rs, unsigned soff) {
+#if DPA_ATTN_LEAN
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %3 offen lds"
+      :
+      : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+      : "memory", "m0");
+#else
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -183,6 +198,7 @@ __device__ __forceinline__ void dma_piece(unsigned lds_addr, unsigned voff, rsrc
       : "=&s"(keep)
       : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
       : "memory");
+#endif
 }
 
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -60,6 +60,13 @@ __device__ __forceinline__ bfrag tr_frag(const char* tile, int rbase, int s, int
   return __builtin_bit_cast(bfrag, v);
 }
 
+// 8 bf16 (one MFMA operand fragment) at LDS byte address addr + imm (imm: a constant that goes into the offset field).
+__device__ __forceinline__ bfrag lds_frag_at(unsigned addr, int imm) {
+  typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+  const u32x4 v = *(lds_u32x4*)(size_t)(addr + (unsigned)imm);
+  return __builtin_bit_cast(bfrag, v);
+}
+
 // The same fragment from two precomputed LDS byte addresses (the 8-row halves jj = 0, 1 of k-step 0 of a tile) plus a
 // constant: a ring of tiles whose slot changes at run time keeps one such address pair per (operand, dt) in registers,
 // adds the slot's offset once per slot and reaches the tile's second k-step through the instruction's offset field,
