@@ -644,6 +644,8 @@ __device__ __forceinline__ void dma_dwords(unsigned lds_addr, unsigned voff, rsr
 }
 
 // dQ: one workgroup = 128 queries, sweeps the keys.
+// (Holding the head-size-64 backward kernels to 168 registers for a third wave per SIMD, amdgpu_waves_per_eu(3), was
+// measured 34 % slower: profiles/r3_attention_bwd_three_waves_experiment.txt.)
 template <int DK, int DV, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int NK = DK / 16, NV = DV / 16, ND = DK / 32, KTILE = 64 * DK * 2, VTILE = 64 * DV * 2, STAGE = KTILE + VTILE;
