@@ -84,7 +84,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from rs[voff] to LDS [lds_addr, lds_addr + 1024).
+// (M0 is written and not restored: nothing else in this kernel reads it)
+#ifndef DPA_GEMM_M0_RESTORE
+#define DPA_GEMM_M0_RESTORE 0
+#endif
 __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, rsrc_t rs) {
+#if DPA_GEMM_M0_RESTORE
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -95,6 +100,15 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, rsrc_t r
       : "=&s"(keep)
       : "s"(lds_addr), "v"(voff), "s"(rs)
       : "memory");
+#else
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds"
+      :
+      : "s"(lds_addr), "v"(voff), "s"(rs)
+      : "memory", "m0");
+#endif
 }
 
 template <int N>
