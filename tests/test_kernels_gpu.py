@@ -1538,3 +1538,20 @@ def test_transposes_of_resident_weights_refresh_in_one_launch_per_shape():
     assert t0.data_ptr() == first[0].data_ptr()
     assert L._WT_CACHE[id(other)][0][0] != L._WEIGHTS_EPOCH      # not resident: still stale until asked for
     assert torch.equal(L.transposed_weight(other), other.detach().t().contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nslabs", [1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 23, 28, 64])
+@pytest.mark.parametrize("out_dtype,accumulate", [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, True)])
+def test_slab_fold_every_slab_count(nslabs, out_dtype, accumulate):
+    """The fold of the weight-gradient slabs asks for eight, then four, then up to three slabs at a time: every
+    count from one slab to the largest split hits a different mix of those branches."""
+    torch.manual_seed(nslabs)
+    N, K = 96, 200
+    ws = torch.randn(nslabs, N, K, device=DEV, dtype=torch.float32)
+    out = torch.randn(N, K, device=DEV, dtype=torch.float32).to(out_dtype)
+    before = out.float().clone()
+    _ops().ws_to(ws, out, accumulate)
+    ref = ws.double().sum(0) + (before.double() if accumulate else 0)
+    tol = 1e-5 if out_dtype == torch.float32 else 5e-3
+    assert rel_err(out.float(), ref.float()) < tol
