@@ -1555,3 +1555,39 @@ def test_slab_fold_every_slab_count(nslabs, out_dtype, accumulate):
     ref = ws.double().sum(0) + (before.double() if accumulate else 0)
     tol = 1e-5 if out_dtype == torch.float32 else 5e-3
     assert rel_err(out.float(), ref.float()) < tol
+
+
+@pytest.mark.gpu
+def test_layernorm_streaming_policy_instantiation():
+    """Activations of 256 MiB and more go through the LayerNorm kernels built with the non-temporal cache policy; the
+    threshold is read once per process, so a child process with DPA_LN_STREAM_MB=0 runs the small-shape checks on
+    those instantiations (plain, with the residual add, backward with the residual gradient)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch, torch.nn.functional as F
+from distributed_pytorch_amd import ops
+torch.manual_seed(0)
+for rows, C in ((300, 768), (129, 1024), (64, 2048)):
+    x = torch.randn(rows, C, device="cuda", dtype=torch.bfloat16)
+    r = torch.randn(rows, C, device="cuda", dtype=torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(C, device="cuda")).to(torch.bfloat16).requires_grad_()
+    b = (0.1 * torch.randn(C, device="cuda")).to(torch.bfloat16).requires_grad_()
+    xs = x.clone().requires_grad_(); rs = r.clone().requires_grad_()
+    s, y = ops.add_layer_norm(xs, rs, w, b, 1e-5)
+    (y.float().square().sum() + s.float().sum()).backward()
+    xr = x.float().requires_grad_(); rr = r.float().requires_grad_()
+    wr = w.detach().float().requires_grad_(); br = b.detach().float().requires_grad_()
+    sr = xr + rr
+    yr = F.layer_norm(sr.to(torch.bfloat16).float(), (C,), wr, br, 1e-5)
+    def rel(a, c): return ((a.float() - c.float()).norm() / (c.float().norm() + 1e-12)).item()
+    assert rel(y, yr) < 1e-2, (rows, C, rel(y, yr))
+    (yr.square().sum() + sr.sum()).backward()
+    assert rel(xs.grad, xr.grad) < 2e-2 and rel(w.grad, wr.grad) < 2e-2 and rel(b.grad, br.grad) < 2e-2, (rows, C)
+print("streaming LayerNorm ok")
+'''
+    env = dict(os.environ, DPA_LN_STREAM_MB="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "streaming LayerNorm ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
