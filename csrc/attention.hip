@@ -122,10 +122,10 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ unsigned drop_key(const long long* seed, int bh) {
-  const unsigned long long s = (unsigned long long)*seed;
+__device__ __forceinline__ unsigned drop_key(unsigned long long s, int bh) {
   return mix32((unsigned)s ^ ((unsigned)bh * 0x27D4EB2Fu)) ^ (unsigned)(s >> 32);
 }
+__device__ __forceinline__ unsigned drop_key(const long long* seed, int bh) { return drop_key((unsigned long long)*seed, bh); }
 __device__ __forceinline__ unsigned drop_threshold(float p) {
   const double t = (double)p * 4294967296.0;
   return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
@@ -819,6 +819,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
                    p.rope_sin, p.rope_pos0 + (p.Tk - p.Tq));
 }
 
+// Timing-only ablations of the dK/dV kernel (benchmarks/ab_build.py ... -DDPA_ATTN_DKV_ABLATE=n, wrong results): 1 = no
+// exponentials / dS arithmetic, 2 = no transposing fragment reads (dO^T, Q^T), 3 = no row fragment reads (Q, dO, row
+// constants), 4 = no dV / dK products, 5 = no per-tile wait + barrier.
+#ifndef DPA_ATTN_DKV_ABLATE
+#define DPA_ATTN_DKV_ABLATE 0
+#endif
+#ifndef DPA_ATTN_DKV_PIN_V
+#define DPA_ATTN_DKV_PIN_V 1
+#endif
 // ------------------------------------------------------------------------------------------
 // Backward, dK/dV: one workgroup = 128 keys of one (batch, kv head); each wave keeps dK^T and
 // dV^T of its 32 keys in registers and sweeps the query heads of the group x the query tiles.
@@ -844,34 +853,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const float c = p.scale * kLog2e;
 
   const int key = kw0 + r;
-  bfrag kf[NK], vf[NV];
-#pragma unroll
-  for (int ks = 0; ks < NK; ++ks) {
-    kf[ks] = zero_frag();
-    if (key < p.Tk) kf[ks] = scaled_frag(kp + (long long)key * p.k_ts + ks * 16 + hh * 8, c);
-  }
-#pragma unroll
-  for (int ks = 0; ks < NV; ++ks) {
-    vf[ks] = zero_frag();
-    if (key < p.Tk) vf[ks] = *reinterpret_cast<const bfrag*>(vp + (long long)key * p.v_ts + ks * 16 + hh * 8);
-  }
   int q_start = k0 - off;
   if (q_start < 0) q_start = 0;
   q_start = (q_start / 64) * 64;
   const int nqt = (p.Tq - q_start + 63) / 64;
-  const int niter = (nqt > 0 ? nqt : 0) * G;
-
-  f32x16 dkacc[ND], dvacc[NDV];
-#pragma unroll
-  for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dkacc[dt][i] = 0.f;
-#pragma unroll
-  for (int dt = 0; dt < NDV; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dvacc[dt][i] = 0.f;
-  const unsigned dthr = DROP ? drop_threshold(p.p_drop) : 0u;
-  const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
+  const int niter = DPA_ATTN_DKV_ABLATE == 6 ? 0 : (nqt > 0 ? nqt : 0) * G;
 
   TileDma<DK> qd;
   TileDma<DV> dd;
@@ -893,16 +879,54 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     }
   };
 
+  // the first tile is on its way before the K / V fragment loads: the two latencies overlap
   if (niter > 0) issue(0, 0);
+
+  bfrag kf[NK], vf[NV];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    kf[ks] = zero_frag();
+    if (key < p.Tk) kf[ks] = scaled_frag(kp + (long long)key * p.k_ts + ks * 16 + hh * 8, c);
+  }
+#pragma unroll
+  for (int ks = 0; ks < NV; ++ks) {
+    vf[ks] = zero_frag();
+    if (key < p.Tk) vf[ks] = *reinterpret_cast<const bfrag*>(vp + (long long)key * p.v_ts + ks * 16 + hh * 8);
+  }
+  // The V fragments are first read inside the tile loop, and a wait the compiler places there runs in every
+  // iteration and also drains the tile prefetch issued just before it (the loads of the prefetch count on the same
+  // counter). Reading them here puts that wait in front of the loop.
+#if DPA_ATTN_DKV_PIN_V
+#pragma unroll
+  for (int ks = 0; ks < NV; ++ks) asm volatile("" : "+v"(vf[ks]));
+#endif
+  f32x16 dkacc[ND], dvacc[NDV];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dkacc[dt][i] = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < NDV; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dvacc[dt][i] = 0.f;
+  const unsigned dthr = DROP ? drop_threshold(p.p_drop) : 0u;
+  const float rkeep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
+  // read once here: a load inside the tile loop would have its wait drain the tile prefetch as well
+  const long long sv = DROP ? *p.seed : 0ll;
+  const unsigned long long seed = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)sv);
+
   for (int it = 0; it < niter; ++it) {
-    wait_dma();
-    __syncthreads();
+    if (DPA_ATTN_DKV_ABLATE != 5 || it == 0) {
+      wait_dma();
+      __syncthreads();
+    }
     if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
     const char* qb = smem + (it & 1) * BUF;
     const char* dob = qb + QTILE;
     const char* stb = qb + QTILE + DOTILE;
     const int qt0 = q_start + (it % nqt) * 64;
-    const unsigned dkey = DROP ? drop_key(p.seed, b * p.nh + kvh * G + it / nqt) : 0u;
+    const unsigned dkey = DROP ? drop_key(seed, b * p.nh + kvh * G + it / nqt) : 0u;
     // 32-query sub-tiles with a (query, key) pair visible to the wave: [sub_lo, sub_hi). A rolled loop:
     // with one `if` per unrolled sub-tile the compiler copies all the dK / dV accumulators at every join.
     const int sub_lo = qt0 + 31 + off >= kw0 ? 0 : (qt0 + 63 + off >= kw0 ? 1 : 2);
@@ -915,15 +939,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       const char* stsub = stb + sub * 128;
       bfrag qf[KCH], dof[NV];
 #pragma unroll
-      for (int ks = 0; ks < KCH; ++ks) qf[ks] = row_frag<DK>(qsub, r, ks, hh);
+      for (int ks = 0; ks < KCH; ++ks) qf[ks] = DPA_ATTN_DKV_ABLATE == 3 ? kf[ks] : row_frag<DK>(qsub, r, ks, hh);
 #pragma unroll
-      for (int ks = 0; ks < NV; ++ks) dof[ks] = row_frag<DV>(dosub, r, ks, hh);
+      for (int ks = 0; ks < NV; ++ks) dof[ks] = DPA_ATTN_DKV_ABLATE == 3 ? vf[ks] : row_frag<DV>(dosub, r, ks, hh);
       f32x16 s, dp;   // start as the row constants of the 16 queries a lane's accumulators belong to
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int rr = 8 * g4 + 4 * hh;
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stsub + rr * 4);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stsub + 256 + rr * 4);
+        const f32x4 l4 = DPA_ATTN_DKV_ABLATE == 3 ? f32x4{-30.f, -30.f, -30.f, -30.f} : *reinterpret_cast<const f32x4*>(stsub + rr * 4);
+        const f32x4 d4 = DPA_ATTN_DKV_ABLATE == 3 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(stsub + 256 + rr * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           s[4 * g4 + j] = l4[j];
@@ -949,9 +973,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-        for (int dt = 0; dt < NDV; ++dt) dot[s2][dt] = tr_frag<DV>(dosub, 0, s2, dt, lane);
+        for (int dt = 0; dt < NDV; ++dt) dot[s2][dt] = DPA_ATTN_DKV_ABLATE == 2 ? vf[(2 * s2 + dt) % NV] : tr_frag<DV>(dosub, 0, s2, dt, lane);
 #pragma unroll
-        for (int dt = 0; dt < DCH; ++dt) qt[s2][dt] = tr_frag<DK>(qsub, 0, s2, dt, lane);
+        for (int dt = 0; dt < DCH; ++dt) qt[s2][dt] = DPA_ATTN_DKV_ABLATE == 2 ? kf[(2 * s2 + dt) % NK] : tr_frag<DK>(qsub, 0, s2, dt, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
       // compare + select only on blocks the diagonal crosses
@@ -962,7 +986,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(s[i]);
+        const float pv = DPA_ATTN_DKV_ABLATE == 1 ? s[i] : __builtin_amdgcn_exp2f(s[i]);
         float pd = pv, dpi = dp[i];
         if (DROP) {   // dropped pairs: P = 0 for dV, dP = 0 before delta is taken off
           const bool keep = drop_keep(dkey, qs0 + acc_row(i, hh), key, dthr);
@@ -970,7 +994,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
           dpi = keep ? (dpi - nd[i]) * rkeep + nd[i] : nd[i];
         }
         s[i] = pd;          // P (dropped and rescaled: the weights dV sees)
-        dp[i] = pv * dpi;   // dS
+        dp[i] = DPA_ATTN_DKV_ABLATE == 1 ? dpi : pv * dpi;   // dS
       }
       if constexpr (ND == NDV && ND <= 4) {
 #pragma unroll
@@ -979,6 +1003,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
           const bfrag dsb = acc_frag(dp, s2);
 #pragma unroll
           for (int dt = 0; dt < ND; ++dt) {
+            if (DPA_ATTN_DKV_ABLATE == 4) {
+              asm volatile("" : "+v"(dvacc[dt]), "+v"(dkacc[dt]) : "v"(dot[s2][dt]), "v"(pb), "v"(qt[s2][dt]), "v"(dsb));
+              continue;
+            }
             dvacc[dt] = mfma32(dot[s2][dt], pb, dvacc[dt]);
             dkacc[dt] = mfma32(qt[s2][dt], dsb, dkacc[dt]);
           }
