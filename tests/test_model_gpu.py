@@ -404,3 +404,48 @@ def test_rope_fallback_backward_keeps_the_incoming_gradient_intact():
     x.grad = None
     loss.backward()
     assert torch.equal(g1, x.grad)
+
+
+@pytest.mark.parametrize("name", ["gpt2", "gqa_rope_swiglu"])
+def test_training_trajectory_bf16_hip_follows_fp32_cpu_engine(name):
+    """40 optimizer steps on a passage the model can learn: the bf16 engine on the HIP kernels (fused AdamW, fused
+    clip, fused head + loss) against the fp32 engine on the CPU, whose trajectory tests/test_reference_trajectory_cpu.py
+    pins to the reference model under the reference's recipe. Same initial weights, batches and learning rates."""
+    from distributed_pytorch_amd.config import Trainconfig
+    from distributed_pytorch_amd.parallel import comm
+    from distributed_pytorch_amd.trainer import build_engine
+    torch.manual_seed(5)
+    cfg = LLMconfig(**{**BASE, **VARIANTS[name]}).finalize()
+    first = LLM(cfg)
+    sd = {k: v.clone() for k, v in first.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    corpus = torch.randint(0, cfg.vocab_size, (1500,), generator=g).repeat(6)
+    B, T, steps = 4, 256, 40
+
+    def batch(it):
+        gb = torch.Generator().manual_seed(100 + it)
+        at = torch.randint(0, corpus.numel() - T - 1, (B,), generator=gb)
+        return torch.stack([corpus[a:a + T] for a in at]), torch.stack([corpus[a + 1:a + T + 1] for a in at])
+
+    def run(device, dtype):
+        model = LLM(cfg)
+        model.load_state_dict(sd)
+        tc = Trainconfig(dtype=dtype, grad_dtype=dtype, learning_rate=2e-3, weight_decay=0.1, grad_clip=1.0)
+        eng = build_engine("single", model, tc, comm.DistInfo(0, 0, 1, torch.device(device), "none"))
+        out = []
+        for it in range(steps):
+            x, y = batch(it)
+            eng.zero_grad()
+            _, loss, _ = eng(x.to(device), y.to(device))
+            loss.backward()
+            eng.clip_grad_norm_(1.0)
+            eng.step(2e-3 * min(1.0, (it + 1) / 5))
+            out.append(loss.item())
+        return out
+
+    want = run("cpu", "fp32")
+    got = run("cuda:0", "bf16")
+    assert want[-1] < 0.6 * want[0], f"the fp32 run has to learn: {want[0]:.3f} -> {want[-1]:.3f}"
+    for s in range(0, steps, 5):
+        a, b = sum(want[s:s + 5]) / 5, sum(got[s:s + 5]) / 5
+        assert abs(a - b) < 0.05 * a + 0.02, f"{name}: steps {s}-{s + 4}: fp32 {a:.4f}, bf16 HIP {b:.4f}\n{want}\n{got}"
