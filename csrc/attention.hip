@@ -413,12 +413,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             for (int ks = 1; ks < NK; ++ks) s[sb + u] = mfma32(kf[u][ks], qf[ks], s[sb + u]);
           }
         }
-        if (need_mask) {
+        if (need_mask) {   // key > qlim, as one compare of a constant against a per-lane bound
+          const int bound = qlim - kv0 - 4 * hh;
 #pragma unroll
           for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-              if (kv0 + sub * 32 + acc_row(i, hh) > qlim) s[sub][i] = -INFINITY;
+              if (sub * 32 + acc_row(i, 0) > bound) s[sub][i] = -INFINITY;
         }
       };
       scores(negm);
@@ -537,9 +538,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           for (int ks = 0; ks < KCH; ++ks) s = mfma32(kf[ks], qf[k0 + ks], s);
         }
         if (mk) {
+          const int bound = qlim - ks0 - 4 * hh;
 #pragma unroll
           for (int i = 0; i < 16; ++i)
-            if (ks0 + acc_row(i, hh) > qlim) s[i] = -INFINITY;
+            if (acc_row(i, 0) > bound) s[i] = -INFINITY;
         }
       };
       scores(negm);
@@ -783,9 +785,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       __builtin_amdgcn_sched_barrier(0);
       // compare + select only where the diagonal or the end of the keys crosses the sub-tile
       if ((ks0 + 31 > wq0) || (ks0 + 32 > p.Tk)) {
+        const int bound = qlim - ks0 - 4 * hh;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (ks0 + acc_row(i, hh) > qlim) s[i] = -INFINITY;
+          if (acc_row(i, 0) > bound) s[i] = -INFINITY;
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -980,9 +983,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       __builtin_amdgcn_sched_barrier(0);
       // compare + select only on blocks the diagonal crosses
       if (kw0 + 31 > qs0 + off) {
+        const int bound = key - qs0 - off - 4 * hh;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (key > qs0 + acc_row(i, hh) + off) s[i] = -INFINITY;
+          if (acc_row(i, 0) < bound) s[i] = -INFINITY;   // key > query
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
