@@ -100,13 +100,16 @@ class DataLoader:
 
 def synthetic_tokens(n: int, vocab_size: int, seed: int = 1729) -> np.ndarray:
     """A deterministic uint16 token stream with a Zipf-like unigram distribution and an
-    end-of-text token (50256 when the vocabulary has it) roughly every 250 tokens."""
+    end-of-text token (50256 when the vocabulary has it) roughly every 250 tokens. ``seed`` picks the
+    sample; which token has which rank is the same for every seed, so that a validation split drawn
+    with another seed comes from the distribution the training split was drawn from."""
     rng = np.random.default_rng(seed)
     v = min(vocab_size, 65535)
     ranks = np.arange(1, v + 1, dtype=np.float64)
     p = 1.0 / ranks ** 1.05
     p /= p.sum()
-    perm = rng.permutation(v)
+    rng.permutation(v)                                   # (keeps the sample stream of seed 1729 as it always was)
+    perm = np.random.default_rng(1729).permutation(v)
     toks = perm[rng.choice(v, size=n, p=p)].astype(np.uint16)
     eot = 50256 if vocab_size > 50256 else v - 1
     toks[rng.random(n) < 1.0 / 250] = eot
@@ -133,7 +136,7 @@ def ensure_synthetic(data_dir: str, n_tokens: int, vocab_size: int, rank: int = 
     d = Path(data_dir)
     if rank == 0:
         d.mkdir(parents=True, exist_ok=True)
-        want = {"vocab_size": int(vocab_size), "n_tokens": int(n_tokens), "seed": int(seed)}
+        want = {"vocab_size": int(vocab_size), "n_tokens": int(n_tokens), "seed": int(seed), "generator": 2}
         meta = d / "synthetic.json"
         try:
             have = json.loads(meta.read_text())

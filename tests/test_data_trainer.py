@@ -13,6 +13,13 @@ def test_synthetic_tokens_shape():
     t = synthetic_tokens(50000, 50304)
     assert t.dtype == np.uint16 and t.max() < 50304 and (t == 50256).sum() > 50
     assert np.array_equal(t, synthetic_tokens(50000, 50304))
+    # another seed is another sample of the SAME unigram distribution (what makes a validation loss on the
+    # synthetic val split comparable with the training loss): the most frequent tokens are the same ones
+    v = synthetic_tokens(50000, 50304, seed=1730)
+    assert not np.array_equal(t, v)
+    top_t = set(np.argsort(np.bincount(t, minlength=50304))[-20:].tolist())
+    top_v = set(np.argsort(np.bincount(v, minlength=50304))[-20:].tolist())
+    assert len(top_t & top_v) >= 15
 
 
 def test_loader_semantics_and_rank_sharding(tmp_path):
