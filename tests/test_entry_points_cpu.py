@@ -48,3 +48,34 @@ def test_sample_script_reads_saved_model(tmp_path):
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("[") and not ln.startswith("[sample]")]
     assert len(rows) == 2 and all(len(x) == 5 + 40 for x in rows), r.stdout[-800:]
     assert all(x[:5] == list(b"To be") and max(x) < 257 for x in rows)
+
+
+@pytest.mark.parametrize("script", ["multi-gpu/ddp/kaggle-ddp.py", "multi-gpu/zero1,2/kaggle-zero2.py"])
+def test_notebook_script_launches_its_own_ranks(script, tmp_path):
+    """Started as a plain process with --nproc 2, a notebook entry script runs the launcher as a child: two gloo
+    ranks train, rank 0's log lines come back through the parent, and the parent exits with the job's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["OMP_NUM_THREADS"] = "2"
+    common = [a if a != "2*32*2" else "2*32*2*2" for a in COMMON]   # two ranks x two micro-steps
+    cmd = [sys.executable, os.path.join(ROOT, script), "--nproc", "2", *common, "--data_dir", str(tmp_path / "data"),
+           "--file_name", str(tmp_path / "out")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "[launch] 2 ranks:" in r.stdout
+    steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step: 3 ")]
+    assert len(steps) == 1 and "train loss" in steps[0], r.stdout[-1500:]
+
+
+def test_launcher_flags_are_stripped_and_a_launched_rank_returns(monkeypatch):
+    from distributed_pytorch_amd import launch
+    argv = ["--nproc", "4", "--moe", "--max_restarts=2", "--n_exp", "8"]
+    monkeypatch.setenv("RANK", "0")
+    launch.self_launch("x.py", argv)            # a launched rank: returns, launcher flags removed
+    assert argv == ["--moe", "--n_exp", "8"]
+    cmd = launch.launcher_command("x.py", argv, 4, max_restarts=2)
+    assert "--nproc-per-node=4" in cmd and "--max-restarts=2" in cmd and "--standalone" in cmd
+    assert cmd[-4:] == ["x.py", "--moe", "--n_exp", "8"]
+    cmd = launch.launcher_command("x.py", argv, 2, port=29511)
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and "--standalone" not in cmd
