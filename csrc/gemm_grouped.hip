@@ -289,6 +289,8 @@ void gemm_grouped_wgrad(const void* a, long long lda, const void* b, long long l
 // Row permutation kernels of the MoE dispatch.
 //   scatter_rows : dst[row_of_pair[j], :] = src[j / k, :]                       (dispatch)
 //   gather_combine: out[t, :] = sum_s gate[t, s] * y[row_of_pair[t*k + s], :]   (combine)
+// A negative row marks a pair that has no row in the buffer (dropped by the capacity bound of the expert-parallel
+// exchange): it is not written, contributes nothing to the combine and gets a zero gate gradient.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void moe_scatter_rows_kernel(const bf16_t* __restrict__ src,
                                                                const long long* __restrict__ row_of_pair,
@@ -299,8 +301,10 @@ __global__ __launch_bounds__(256) void moe_scatter_rows_kernel(const bf16_t* __r
        i += (long long)gridDim.x * blockDim.x) {
     const long long j = i / nvec;
     const int c = (int)(i - j * nvec) * 8;
+    const long long row = row_of_pair[j];
+    if (row < 0) continue;
     const u32x4 v = *reinterpret_cast<const u32x4*>(src + (j / k) * C + c);
-    *reinterpret_cast<u32x4*>(dst + row_of_pair[j] * C + c) = v;
+    *reinterpret_cast<u32x4*>(dst + row * C + c) = v;
   }
 }
 
@@ -316,9 +320,11 @@ __global__ __launch_bounds__(256) void moe_gather_combine_kernel(const bf16_t* _
     const int c = (int)(i - t * nvec) * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < k; ++s) {
+      const long long row = row_of_pair[t * k + s];
+      if (row < 0) continue;
       const float gt = gates ? bf16_to_f32(gates[t * k + s]) : 1.f;
       float v[8];
-      load8(y + row_of_pair[t * k + s] * C + c, v);
+      load8(y + row * C + c, v);
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += gt * v[q];
     }
@@ -337,6 +343,10 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(const bf16_t* __re
   const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= npairs) return;
   const long long t = pair / k, row = row_of_pair[pair];
+  if (row < 0) {   // wave-uniform
+    if (lane == 0) dgate[pair] = 0.f;
+    return;
+  }
   const float gt = bf16_to_f32(gates[pair]);
   float dot = 0.f;
   for (int c = lane * 8; c < C; c += 512) {

@@ -87,29 +87,29 @@ def plan_dense(topk_indices: torch.Tensor, n_experts: int):
 
 class _ScatterRowsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, row_of_pair, k, rows):
+    def forward(ctx, x, row_of_pair, k, rows, tables):
         ctx.save_for_backward(row_of_pair)
         ctx.k = k
-        return ops().moe_scatter_rows(x.contiguous(), row_of_pair, k, rows)
+        return ops().moe_scatter_rows(x.contiguous(), row_of_pair, k, rows, *(tables or ()))
 
     @staticmethod
     def backward(ctx, g):
         (row_of_pair,) = ctx.saved_tensors
-        return ops().moe_gather_combine(g.contiguous(), row_of_pair, None, ctx.k), None, None, None
+        return ops().moe_gather_combine(g.contiguous(), row_of_pair, None, ctx.k), None, None, None, None
 
 
 class _GatherCombineFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, row_of_pair, gates, k):
+    def forward(ctx, y, row_of_pair, gates, k, tables):
         yc, gc = y.contiguous(), gates.contiguous()
-        ctx.save_for_backward(yc, row_of_pair, gc)
+        ctx.save_for_backward(yc, row_of_pair, gc, *(tables or ()))
         return ops().moe_gather_combine(yc, row_of_pair, gc, k)
 
     @staticmethod
     def backward(ctx, dout):
-        y, row_of_pair, gates = ctx.saved_tensors
-        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates)
-        return dy, None, dgate.to(gates.dtype), None
+        y, row_of_pair, gates, *tables = ctx.saved_tensors
+        dy, dgate = ops().moe_combine_bwd(dout.contiguous(), y, row_of_pair, gates, *tables)
+        return dy, None, dgate.to(gates.dtype), None, None
 
 
 def _rows_hip_ok(x, row_of_pair) -> bool:
@@ -117,19 +117,25 @@ def _rows_hip_ok(x, row_of_pair) -> bool:
         and row_of_pair.numel() > 0
 
 
-def scatter_rows(x: torch.Tensor, row_of_pair: torch.Tensor, k: int, rows: int) -> torch.Tensor:
-    """out[row_of_pair[t*k + s]] = x[t] (other rows zero); differentiable in x."""
+def scatter_rows(x: torch.Tensor, row_of_pair: torch.Tensor, k: int, rows: int, tables=None) -> torch.Tensor:
+    """out[row_of_pair[t*k + s]] = x[t] (other rows zero); differentiable in x. A negative row drops its pair.
+    ``tables`` = (seg_start, counts, seg_rows), int64 [segments]: the buffer is a sequence of padded segments whose
+    first ``counts`` rows are all written by pairs, so only the remaining rows are zero-filled instead of all."""
     if _rows_hip_ok(x, row_of_pair):
-        return _ScatterRowsFn.apply(x, row_of_pair, k, rows)
-    out = x.new_zeros(rows, x.shape[1])
-    return out.index_copy(0, row_of_pair, x.repeat_interleave(k, 0))
+        return _ScatterRowsFn.apply(x, row_of_pair, k, rows, tables)
+    out = x.new_zeros(rows + 1, x.shape[1])     # row `rows` swallows the dropped pairs
+    dest = torch.where(row_of_pair < 0, torch.full_like(row_of_pair, rows), row_of_pair)
+    return out.index_copy(0, dest, x.repeat_interleave(k, 0))[:rows]
 
 
-def gather_combine(y: torch.Tensor, row_of_pair: torch.Tensor, gates: torch.Tensor, k: int) -> torch.Tensor:
-    """out[t] = sum_s gates[t, s] * y[row_of_pair[t*k + s]]; differentiable in y and gates."""
+def gather_combine(y: torch.Tensor, row_of_pair: torch.Tensor, gates: torch.Tensor, k: int, tables=None) -> torch.Tensor:
+    """out[t] = sum_s gates[t, s] * y[row_of_pair[t*k + s]]; differentiable in y and gates. A pair with a negative
+    row contributes nothing. ``tables`` as in ``scatter_rows``, for the gradient buffer of ``y``."""
     if _rows_hip_ok(y, row_of_pair) and gates.dtype == torch.bfloat16:
-        return _GatherCombineFn.apply(y, row_of_pair, gates, k)
-    picked = y[row_of_pair].view(-1, k, y.shape[1])
+        return _GatherCombineFn.apply(y, row_of_pair, gates, k, tables)
+    y_ext = torch.cat([y, y.new_zeros(1, y.shape[1])], 0)
+    src = torch.where(row_of_pair < 0, torch.full_like(row_of_pair, y.shape[0]), row_of_pair)
+    picked = y_ext[src].view(-1, k, y.shape[1])
     return (picked * gates.unsqueeze(-1).to(picked.dtype)).sum(1)
 
 

@@ -146,7 +146,6 @@ class ExpertParallelDispatcher:
         N, k = topk_indices.shape
         # expert-sorted (== destination-rank-sorted) send order, computed on the device
         row_of_pair, counts = ops.plan_dense(topk_indices, moe.n_routed)   # counts: rows per expert (global ids)
-        xs = ops.scatter_rows(x_flat, row_of_pair, k, N * k)
         st = dict(moe=moe, x_flat=x_flat, row_of_pair=row_of_pair, gates=topk_gates, k=k, per=per, log=[])
         self.last_log = st["log"]
         if self.capacity > 0:
@@ -160,22 +159,28 @@ class ExpertParallelDispatcher:
             sent = send_cnt.sum(1)
             lost = (want - sent).sum()
             self.dropped = lost if self.dropped is None else self.dropped + lost
-            j = torch.arange(cap, device=xs.device)
-            valid = (j[None, :] < sent[:, None]).reshape(-1)
-            src = (seg_start[:, None] + j[None, :]).clamp(max=N * k - 1).reshape(-1)
-            send = xs.index_select(0, src) * valid[:, None].to(xs.dtype)
+            # The rows go from x straight into the padded send layout (``cap`` rows per destination): the pair at
+            # place j of its destination's expert-sorted run lands in row dest * cap + j, a pair past the capacity
+            # gets no row (-1), and the rows no pair fills are the only ones zeroed. Index arithmetic on [pairs]
+            # integers; the activations are moved once, by the scatter kernel.
+            dest = torch.div(topk_indices.reshape(-1), per, rounding_mode="floor")
+            j = row_of_pair - seg_start[dest]
+            row_cap = torch.where(j < cap, dest * cap + j, torch.full_like(j, -1))
+            lanes = torch.arange(W, device=x_flat.device, dtype=torch.int64)
+            tables = (lanes * cap, sent.to(torch.int64).contiguous(), torch.full_like(lanes, cap))
+            send = ops.scatter_rows(x_flat, row_cap, k, W * cap, tables)
             recv_cnt = torch.empty_like(send_cnt)
             comm.all_to_all(recv_cnt, send_cnt.contiguous(), group=self.group)   # [src rank][local expert]
-            st.update(cap=cap, src=src, valid=valid, recv_cnt=recv_cnt, npairs=N * k, in_splits=None, out_splits=None)
+            st.update(cap=cap, row_cap=row_cap, tables=tables, recv_cnt=recv_cnt, in_splits=None, out_splits=None)
             n_out = W * cap
         else:
+            send = ops.scatter_rows(x_flat, row_of_pair, k, N * k)              # enqueued ahead of the host read below
             recv_counts = torch.empty_like(counts)
             comm.all_to_all(recv_counts, counts, group=self.group)              # [src rank][local expert]
             recv_mat = recv_counts.view(W, per)
             # the one host read of the layer: rows sent to / received from each rank (the all-to-all splits)
             counts_h, recv_h = torch.stack([counts.view(W, per).sum(1), recv_mat.sum(1)]).tolist()
             counts_h, recv_h = [int(v) for v in counts_h], [int(v) for v in recv_h]
-            send = xs
             st.update(recv_mat=recv_mat, in_splits=counts_h, out_splits=recv_h)
             n_out = sum(recv_h)
         send_w = _WaitGrad.apply(send, st, "dispatch_bwd", False)
@@ -266,9 +271,8 @@ class ExpertParallelDispatcher:
         y_back = _Exchange.apply(st.pop("y_w"), st.pop("back_buf"), st["out_splits"], st["in_splits"], self.group, st,
                                  "return_bwd", False)
         if self.capacity > 0:
-            y_sorted = torch.zeros(st["npairs"], y_back.shape[1], dtype=y_back.dtype, device=y_back.device)
-            y_sorted = y_sorted.index_add(0, st["src"], y_back * st["valid"][:, None].to(y_back.dtype))
-            return ops.gather_combine(y_sorted, st["row_of_pair"], st["gates"], st["k"]).to(st["x_flat"].dtype)
+            # padding rows of the returned buffer are never read: every pair gathers its own row, a dropped pair none
+            return ops.gather_combine(y_back, st["row_cap"], st["gates"], st["k"], st["tables"]).to(st["x_flat"].dtype)
         return ops.gather_combine(y_back, st["row_of_pair"], st["gates"], st["k"]).to(st["x_flat"].dtype)
 
 

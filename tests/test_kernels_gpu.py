@@ -724,6 +724,58 @@ def test_dense_plan_scatter_and_combine(N, E, k, C):
         assert rel_err(a, b) < 1.5e-2
 
 
+@pytest.mark.parametrize("N,W,k,C,cap", [(2048, 4, 2, 768, 512), (600, 2, 2, 128, 1000), (1000, 8, 1, 256, 64)])
+def test_scatter_into_capacity_layout_with_dropped_pairs(N, W, k, C, cap):
+    """The static-capacity send layout of the expert-parallel exchange: ``cap`` rows per destination, pairs past a
+    destination's capacity carry row -1 (not written, nothing combined, zero gate gradient), only the rows no pair
+    fills are zeroed (the allocator hands out NaN-filled blocks here). Forward and backward against the PyTorch
+    statement of the same functions."""
+    import os
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(1)
+    dest = torch.randint(0, W, (N * k,), device=DEV)
+    dest[: N * k // 3] = 0                                   # one busy destination, so that some capacities overflow
+    order = torch.argsort(dest, stable=True)
+    place = torch.empty_like(order)
+    counts = torch.zeros(W, dtype=torch.int64, device=DEV).scatter_add_(0, dest, torch.ones_like(dest))
+    start = torch.cumsum(counts, 0) - counts
+    place[order] = torch.arange(N * k, device=DEV) - start[dest[order]]
+    row = torch.where(place < cap, dest * cap + place, torch.full_like(place, -1))
+    sent = counts.clamp(max=cap)
+    lanes = torch.arange(W, device=DEV)
+    tables = (lanes * cap, sent.contiguous(), torch.full_like(lanes, cap))
+    x = torch.randn(N, C, device=DEV, dtype=torch.bfloat16)
+    gates = torch.softmax(torch.randn(N, k, device=DEV), 1).to(torch.bfloat16)
+    dout = torch.randn(N, C, device=DEV, dtype=torch.bfloat16)
+    poison = [torch.full((W * cap, C), float("nan"), device=DEV, dtype=torch.bfloat16) for _ in range(3)]
+    del poison                                               # the caching allocator reuses these blocks below
+
+    def run(eager):
+        if eager:
+            os.environ["DPA_FORCE_EAGER"] = "1"
+        try:
+            xi = x.clone().float().requires_grad_() if eager else x.clone().requires_grad_()
+            gi = gates.clone().float().requires_grad_() if eager else gates.clone().requires_grad_()
+            xs = ops.scatter_rows(xi, row, k, W * cap, tables)
+            ys = xs * 2.0
+            ys.retain_grad()
+            out = ops.gather_combine(ys, row, gi, k, tables)
+            out.backward(dout.float() if eager else dout)
+            return xs.detach(), out, xi.grad, gi.grad, ys.grad
+        finally:
+            os.environ.pop("DPA_FORCE_EAGER", None)
+
+    got, want = run(False), run(True)
+    assert bool((row < 0).any()) == bool((counts > cap).any())   # (the second case drops nothing)
+    for a, b in zip(got, want):
+        assert torch.isfinite(a.float()).all()
+        assert rel_err(a, b) < 1.5e-2
+    valid = torch.zeros(W * cap, dtype=torch.bool, device=DEV)
+    valid[row[row >= 0]] = True
+    assert (got[0][~valid] == 0).all() and (got[4][~valid] == 0).all()      # padding rows: zero data, zero gradient
+    assert (got[3].reshape(-1)[row < 0] == 0).all()                          # dropped pairs: zero gate gradient
+
+
 @pytest.mark.parametrize("B,Tq,Tk,nh,nkv,hs,dv", [(2, 256, 256, 8, 8, 32, 32), (2, 200, 200, 4, 1, 48, 32),
                                                   (1, 128, 128, 4, 2, 96, 96), (2, 1, 130, 4, 4, 32, 32)])
 def test_flash_attention_padded_head_sizes(B, Tq, Tk, nh, nkv, hs, dv):

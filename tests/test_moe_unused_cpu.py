@@ -22,3 +22,27 @@ def test_experts_without_tokens_get_zero_gradients():
         assert g is not None and e.expert.c_proj.weight.grad is not None
         counts += int(g.abs().sum() > 0)
     assert 0 < counts <= 4            # only the experts that saw tokens have non-zero gradients
+
+
+def test_row_scatter_and_combine_statements_drop_negative_rows():
+    """PyTorch statement of the row scatter / combine with dropped pairs (row -1): the pair writes nothing, adds
+    nothing to its token's output and passes no gradient."""
+    import torch
+    from distributed_pytorch_amd import ops
+    torch.manual_seed(0)
+    N, k, C, rows = 6, 2, 4, 9
+    row = torch.tensor([0, 3, -1, 4, 8, -1, 1, 2, -1, -1, 5, 6])
+    x = torch.randn(N, C, requires_grad=True)
+    gates = torch.rand(N, k, requires_grad=True)
+    xs = ops.scatter_rows(x, row, k, rows)
+    assert xs.shape == (rows, C) and (xs[7] == 0).all()
+    for p in range(N * k):
+        if row[p] >= 0:
+            assert torch.equal(xs[row[p]], x[p // k].detach())
+    out = ops.gather_combine(xs * 3.0, row, gates, k)
+    keep = (row >= 0).view(N, k).float()
+    want = 3.0 * (gates.detach() * keep).sum(1, keepdim=True) * x.detach()
+    assert torch.allclose(out, want, atol=1e-6)
+    out.sum().backward()
+    assert torch.allclose(x.grad, 3.0 * (gates.detach() * keep).sum(1, keepdim=True).expand(N, C), atol=1e-6)
+    assert (gates.grad[keep == 0] == 0).all()
