@@ -266,11 +266,15 @@ constexpr float kSumHi = 1.0e9f, kSumLo = 1.0e-9f;
 
 // Timing-only ablations of the forward at head size 64 (benchmarks/ab_build.py ... -DDPA_ATTN_ABLATE=n, wrong
 // results): 1 = no exponential and never a redo, 2 = additionally no P V products. Measured at B64 T1024: 173.1 us
-// -> 170.3 (1) -> 138.9 (2): the exponentials are already hidden, a product is not.
+// -> 170.3 (1) -> 138.9 (2): the exponentials are already hidden, a product is not. 3 = the V fragments come by row
+// reads (ds_read_b128, the same bytes at the faster of the two LDS access patterns), 4 = no V fragment reads at all,
+// 5 = no K fragment reads: what the LDS pipe itself costs.
 #ifndef DPA_ATTN_ABLATE
 #define DPA_ATTN_ABLATE 0
 #endif
-__device__ __forceinline__ float fwd_exp2(float x) { return DPA_ATTN_ABLATE ? x : __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fwd_exp2(float x) {
+  return (DPA_ATTN_ABLATE == 1 || DPA_ATTN_ABLATE == 2) ? x : __builtin_amdgcn_exp2f(x);
+}
 
 // Timing trace of the forward (benchmark builds with -DDPA_ATTN_TRACE only): the four waves of one workgroup stamp
 // the shader clock at seven points of each of their first 16 key tiles into LDS; at the end the low words replace
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
           for (int u = 0; u < KSUB; ++u)
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) kf[u][ks] = row_frag<DK>(kb, (sb + u) * 32 + r, ks, hh);
+            for (int ks = 0; ks < NK; ++ks) kf[u][ks] = DPA_ATTN_ABLATE == 5 ? qf[ks] : row_frag<DK>(kb, (sb + u) * 32 + r, ks, hh);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < KSUB; ++u) {
@@ -430,7 +434,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int dt = 0; dt < ND; ++dt) vf[u][s2][dt] = tr_frag<DV>(vb, u * 32, s2, dt, lane);
+          for (int dt = 0; dt < ND; ++dt) {
+            if (DPA_ATTN_ABLATE == 3) vf[u][s2][dt] = row_frag<DV>(vb, u * 32 + r, 2 * dt + s2, hh);
+            else if (DPA_ATTN_ABLATE == 4) vf[u][s2][dt] = qf[2 * dt + s2];
+            else vf[u][s2][dt] = tr_frag<DV>(vb, u * 32, s2, dt, lane);
+          }
       __builtin_amdgcn_sched_barrier(0);
       float rs = 0.f;
 #pragma unroll
