@@ -268,7 +268,8 @@ constexpr float kSumHi = 1.0e9f, kSumLo = 1.0e-9f;
 // results): 1 = no exponential and never a redo, 2 = additionally no P V products. Measured at B64 T1024: 173.1 us
 // -> 170.3 (1) -> 138.9 (2): the exponentials are already hidden, a product is not. 3 = the V fragments come by row
 // reads (ds_read_b128, the same bytes at the faster of the two LDS access patterns), 4 = no V fragment reads at all,
-// 5 = no K fragment reads: what the LDS pipe itself costs.
+// 5 = no K fragment reads: what the LDS pipe itself costs. 6 = no K/V transfers after the first tile's (the loop
+// computes on whatever the LDS holds): what the trip from L2 / HBM into the LDS costs.
 #ifndef DPA_ATTN_ABLATE
 #define DPA_ATTN_ABLATE 0
 #endif
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     else wait_dma();
     __syncthreads();   // tile t has landed for every wave; every wave is done with tile t - 1's buffer
     DPA_ATR(1);
-    if (t + NST - 1 < ntiles) {
+    if (t + NST - 1 < ntiles && DPA_ATTN_ABLATE != 6) {
       int sn = st_cur + NST - 1;
       if (sn >= NST) sn -= NST;
       const unsigned nb = lds0 + sn * STAGE;
@@ -1062,7 +1063,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 template <int DK, int DV, bool DROP>
 static void fwd_launch(const AttnParams& p, hipStream_t st) {
   const int nqt = (p.Tq + 127) / 128;
-  const size_t lds = (size_t)fwd_stages(DK, DV) * (64 * DK * 2 + 64 * DV * 2);
+  size_t lds = (size_t)fwd_stages(DK, DV) * (64 * DK * 2 + 64 * DV * 2);
+  // benchmark aid: unused LDS bytes added to the request, which bounds the workgroups per CU (160 KiB each)
+  static const long pad = getenv("DPA_ATTN_FWD_PAD_LDS") ? atol(getenv("DPA_ATTN_FWD_PAD_LDS")) : 0;
+  if (pad > 0 && lds + (size_t)pad <= 160 * 1024) lds += (size_t)pad;
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DK, DV, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
