@@ -50,15 +50,18 @@ class _WaitGrad(torch.autograd.Function):
     node in front of the local experts also opens the deferral window for their weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, st, key, open_defer):
-        ctx.st, ctx.key, ctx.open_defer = st, key, open_defer
+    def forward(ctx, x, box, key, open_defer):
+        # ``box`` is the layer's mailbox (work handles in flight by key, the event log), NOT the dispatcher's state
+        # dict: that one holds tensors whose grad_fn is this very node, and a node that held it back would close a
+        # reference cycle through the autograd graph that nothing ever collects (gigabytes per step).
+        ctx.box, ctx.key, ctx.open_defer = box, key, open_defer
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        pending = ctx.st.pop(ctx.key, None)
+        pending = ctx.box.pop(ctx.key, None)
         if pending is not None:
-            ctx.st["log"].append(("wait", ctx.key))
+            ctx.box["log"].append(("wait", ctx.key))
             pending[0].wait()
         if ctx.open_defer:
             from ..ops.linear import begin_deferred_wgrads
@@ -74,8 +77,8 @@ class _Exchange(torch.autograd.Function):
     issue, i.e. while their input gradient is on the links."""
 
     @staticmethod
-    def forward(ctx, x, out, in_splits, out_splits, group, st, key, flush):
-        ctx.meta = (tuple(x.shape), in_splits, out_splits, group, st, key, flush)
+    def forward(ctx, x, out, in_splits, out_splits, group, box, key, flush):
+        ctx.meta = (tuple(x.shape), in_splits, out_splits, group, box, key, flush)   # box: see _WaitGrad
         return out.view_as(out)
 
     @staticmethod
@@ -146,7 +149,8 @@ class ExpertParallelDispatcher:
         N, k = topk_indices.shape
         # expert-sorted (== destination-rank-sorted) send order, computed on the device
         row_of_pair, counts = ops.plan_dense(topk_indices, moe.n_routed)   # counts: rows per expert (global ids)
-        st = dict(moe=moe, x_flat=x_flat, row_of_pair=row_of_pair, gates=topk_gates, k=k, per=per, log=[])
+        box = {"log": []}            # what the autograd nodes of this layer share: pending work handles and the log
+        st = dict(moe=moe, x_flat=x_flat, row_of_pair=row_of_pair, gates=topk_gates, k=k, per=per, log=box["log"], box=box)
         self.last_log = st["log"]
         if self.capacity > 0:
             cap = -(-int(self.capacity * N * k) // W)
@@ -183,7 +187,7 @@ class ExpertParallelDispatcher:
             counts_h, recv_h = [int(v) for v in counts_h], [int(v) for v in recv_h]
             st.update(recv_mat=recv_mat, in_splits=counts_h, out_splits=recv_h)
             n_out = sum(recv_h)
-        send_w = _WaitGrad.apply(send, st, "dispatch_bwd", False)
+        send_w = _WaitGrad.apply(send, box, "dispatch_bwd", False)
         st["send_w"] = send_w
         st["recv_buf"], st["work"] = self._issue(st, send_w, n_out, st["in_splits"], st["out_splits"], "dispatch")
         return st
@@ -212,7 +216,7 @@ class ExpertParallelDispatcher:
         moe, per, W = st["moe"], st["per"], self.world
         st.pop("work").wait()
         st["log"].append(("wait", "dispatch"))
-        recv = _Exchange.apply(st["send_w"], st.pop("recv_buf"), st["in_splits"], st["out_splits"], self.group, st,
+        recv = _Exchange.apply(st["send_w"], st.pop("recv_buf"), st["in_splits"], st["out_splits"], self.group, st["box"],
                                "dispatch_bwd", True)
         R = recv.shape[0]
         if self.capacity > 0:
@@ -257,7 +261,7 @@ class ExpertParallelDispatcher:
             n_back = sum(st["in_splits"])
         # the node in front of the local experts' backward: waits for the reverse of the return exchange and opens
         # the deferral window for the experts' weight gradients
-        y_w = _WaitGrad.apply(y_recv, st, "return_bwd", True)
+        y_w = _WaitGrad.apply(y_recv, st["box"], "return_bwd", True)
         st["y_w"] = y_w
         st["back_buf"], st["work"] = self._issue(st, y_w, n_back, st["out_splits"], st["in_splits"], "return")
         return st
@@ -268,7 +272,7 @@ class ExpertParallelDispatcher:
             st = self.mid(st)
         st.pop("work").wait()
         st["log"].append(("wait", "return"))
-        y_back = _Exchange.apply(st.pop("y_w"), st.pop("back_buf"), st["out_splits"], st["in_splits"], self.group, st,
+        y_back = _Exchange.apply(st.pop("y_w"), st.pop("back_buf"), st["out_splits"], st["in_splits"], self.group, st["box"],
                                  "return_bwd", False)
         if self.capacity > 0:
             # padding rows of the returned buffer are never read: every pair gathers its own row, a dropped pair none
