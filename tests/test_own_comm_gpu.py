@@ -177,6 +177,39 @@ def test_engines_over_the_own_communicator_match_single(own_as_default_group, ow
         assert abs(a - b) < 3e-2 * abs(b) + 1e-3, (mode, got, ref)
 
 
+@pytest.mark.parametrize("mode", ["ddp", "zero2", "fsdp", "ep", "ep_fsdp"])
+def test_engine_steps_over_the_own_communicator_hold_no_memory(own_as_default_group, own, mode):
+    """Work handles of the own communicator keep their operands until the collective has finished; none of them (nor
+    anything else of a step) may outlive the step: allocated memory is flat from step 4 to step 12 with the cyclic
+    collector off."""
+    import gc
+    from distributed_pytorch_amd.config import LLMconfig, Trainconfig
+    from distributed_pytorch_amd.models.llm import LLM
+    from distributed_pytorch_amd.parallel import comm
+    from distributed_pytorch_amd.trainer import build_engine
+    from test_dist_gpu import _run
+    moe = dict(non_linearity="swiglu", moe=True, n_exp=4, n_shared=1, n_act=2) if mode.startswith("ep") else dict(non_linearity="gelu")
+    cfg = LLMconfig(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="mha",
+                    pos_emb="learn", **moe).finalize()
+    tc = Trainconfig(dtype="bf16", learning_rate=1e-3, bucket_mb=0.5)
+    torch.manual_seed(1)
+    eng = build_engine(mode, LLM(cfg), tc, own_as_default_group)
+    gc.collect()
+    gc.disable()
+    try:
+        _run(eng, cfg, steps=4)
+        torch.cuda.synchronize()
+        at4 = torch.cuda.memory_allocated()
+        _run(eng, cfg, steps=8)
+        torch.cuda.synchronize()
+        at12 = torch.cuda.memory_allocated()
+    finally:
+        gc.enable()
+        comm.deregister_buffers()
+    assert at12 <= at4 + (1 << 20), f"allocated memory grew from {at4} to {at12} bytes over 8 steps"
+    assert own.async_error() == ""
+
+
 def test_buffer_registration(own):
     """A registered persistent buffer is used like any other; it is deregistered before it is freed."""
     t = torch.randn(1 << 22, device="cuda").bfloat16()
