@@ -177,8 +177,17 @@ def transposed_weight(w: torch.Tensor) -> torch.Tensor:
     wt = ops().transpose_bf16(w.detach())
     if len(_WT_CACHE) > 4096:
         _WT_CACHE.clear()
-    _WT_CACHE[key] = (stamp, wt, weakref.ref(w))
+    # The entry leaves with its weight: a weight that is a fresh tensor object every step (a view handed out by an
+    # autograd node, e.g. the diverted head weight of the split tied tail) would otherwise leave one transposed copy
+    # behind per step.
+    _WT_CACHE[key] = (stamp, wt, weakref.ref(w, lambda _r, k=key: _drop_dead_transpose(k)))
     return wt
+
+
+def _drop_dead_transpose(key) -> None:
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent[2]() is None:
+        del _WT_CACHE[key]
 
 
 # 256 x 256 output tiles below which the library serves a product: half a round of the 256 workgroups. GPT-2-124M at

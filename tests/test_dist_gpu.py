@@ -126,7 +126,8 @@ def test_expert_parallel_steps_hold_no_memory(one_rank_group, kind, capacity):
     assert at12 <= at4 + (1 << 20), f"allocated memory grew from {at4} to {at12} bytes over 8 steps"
 
 
-@pytest.mark.parametrize("mode", ["single", "ddp", "zero2", "fsdp", "fsdp_vp", "single_moe"])
+@pytest.mark.parametrize("mode", ["single", "ddp", "zero2", "fsdp", "fsdp_vp", "single_moe", "ddp_split", "single_block",
+                                  "fsdp_block"])
 def test_engine_steps_hold_no_memory(one_rank_group, mode):
     """The same for the dense engines and the local MoE path: allocated memory is flat from step 4 to step 12 with the
     cyclic collector off."""
@@ -135,13 +136,17 @@ def test_engine_steps_hold_no_memory(one_rank_group, mode):
     from distributed_pytorch_amd.models.llm import LLM
     from distributed_pytorch_amd.trainer import build_engine
     moe = mode.endswith("_moe")
+    block = mode.endswith("_block")     # whole-block recomputation
     cfg = LLMconfig(vocab_size=1024, block_size=256, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="gqa", n_kv_heads=2,
-                    pos_emb="rope", non_linearity="swiglu", moe=moe, n_exp=4, n_shared=1, n_act=2).finalize()
+                    pos_emb="rope", non_linearity="swiglu", moe=moe, n_exp=4, n_shared=1, n_act=2, act_recomp=block,
+                    act_recomp_scope="block").finalize()
     tc = Trainconfig(learning_rate=1e-3, bucket_mb=0.5, dtype="bf16")
     if mode.endswith("_vp"):
         tc.vocab_parallel, mode = True, mode[:-3]
+    if mode.endswith("_split"):         # the tied head weight reaches the loss as a fresh view tensor every step
+        tc.tied_tail, mode = "split", mode[:-6]
     torch.manual_seed(1)
-    eng = build_engine(mode.replace("_moe", ""), LLM(cfg), tc, one_rank_group)
+    eng = build_engine(mode.replace("_moe", "").replace("_block", ""), LLM(cfg), tc, one_rank_group)
     gc.collect()
     gc.disable()
     try:

@@ -1643,3 +1643,21 @@ print("streaming LayerNorm ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "streaming LayerNorm ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_transposed_weight_cache_entries_leave_with_their_weight():
+    """The cache of transposed weights is keyed by the weight tensor object; an entry whose weight has died is removed
+    with it (a weight handed out as a fresh view every step once left one transposed copy behind per step)."""
+    import importlib
+    lin = importlib.import_module("distributed_pytorch_amd.ops.linear")
+    base = torch.randn(256, 128, device=DEV, dtype=torch.bfloat16)
+    keep = base.view_as(base)
+    wt = lin.transposed_weight(keep)
+    assert torch.equal(wt, base.t().contiguous())
+    n0 = len(lin._WT_CACHE)
+    for _ in range(10):
+        v = base.view_as(base)
+        assert torch.equal(lin.transposed_weight(v), wt)
+        del v
+    assert len(lin._WT_CACHE) == n0
+    assert lin.transposed_weight(keep) is wt          # the live weight's entry is still served from the cache
