@@ -12,7 +12,9 @@ stored both as dataclass instances (like the reference) and as plain dicts
 (``*_config_dict``) that load with ``weights_only=True``.
 
 ``save_resume`` / ``load_resume`` add what the reference lacks: optimizer state (per rank for
-sharded engines), iteration counter, RNG and data-loader state.
+sharded engines), iteration counter, RNG and data-loader state. A job restarted on ANOTHER number of
+ranks reads the files of all ranks of the job that wrote them and re-cuts the optimizer shards
+(data-parallel, ZeRO and fully sharded engines; the expert-parallel engines refuse).
 """
 from __future__ import annotations
 
@@ -59,6 +61,33 @@ def _read_marker(path: str):
         return None
 
 
+def _marker_worlds(path: str) -> dict:
+    """{iteration: world size it was written with} for the generations the marker names ({} for markers of
+    earlier versions, which did not record the previous generation's)."""
+    import json
+    try:
+        with open(_marker(path)) as f:
+            m = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    out = {}
+    if m.get("world") is not None and m.get("iter") is not None:
+        out[int(m["iter"])] = int(m["world"])
+    if m.get("prev") is not None and m.get("prev_world") is not None:
+        out[int(m["prev"])] = int(m["prev_world"])
+    return out
+
+
+def _agreed_world(path: str, it, rank: int, device, default: int) -> int:
+    """World size of the job that wrote generation ``it``, as RANK 0 reads the marker, on every rank. Collective."""
+    w = default
+    if rank == 0 and it is not None:
+        w = _marker_worlds(path).get(int(it), default)
+    t = torch.tensor([w], dtype=torch.int64, device=device)
+    comm.broadcast(t, src=0)
+    return int(t.item())
+
+
 def _all_ranks(flag: bool, device) -> bool:
     """True iff ``flag`` holds on every rank."""
     t = torch.tensor([1.0 if flag else 0.0], device=device)
@@ -101,6 +130,7 @@ def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: in
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     device = getattr(engine, "device", torch.device("cpu"))
     old = _agreed_marker(path, rank, device)
+    old_worlds = _marker_worlds(path) if rank == 0 else {}
     payload = {
         "iter": it,
         "world": world,
@@ -119,15 +149,18 @@ def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: in
     prev = old[0] if old is not None and old[0] != it else (old[1] if old is not None else None)
     if rank == 0:
         with open(_marker(path) + ".tmp", "w") as f:
-            json.dump({"iter": it, "prev": prev, "world": world}, f)
+            json.dump({"iter": it, "prev": prev, "world": world, "prev_world": old_worlds.get(prev)}, f)
         os.replace(_marker(path) + ".tmp", _marker(path))
     comm.barrier()                      # the generation is committed
     if old is not None:
         for stale in {old[0], old[1]} - {it, prev, None}:
-            try:
-                os.remove(_gen_file(path, stale, rank))
-            except OSError:
-                pass
+            # own file; rank 0 also clears what the ranks of a LARGER earlier job left (nobody else would)
+            extra = range(world, old_worlds.get(stale, world)) if rank == 0 else ()
+            for r in (rank, *extra):
+                try:
+                    os.remove(_gen_file(path, stale, r))
+                except OSError:
+                    pass
 
 
 def resume_candidates(path: str, rank: int = 0, device=None) -> list[int | None]:
@@ -148,9 +181,14 @@ def find_resume(path: str, rank: int, device) -> int | None | bool:
     """The newest generation whose file exists on EVERY rank: its iteration, None for the legacy
     single-generation layout, or False when there is nothing to resume from. Collective: every rank walks
     rank 0's candidate list, so all of them issue the same sequence of all-reduces."""
+    world = comm.world_size()
     for it in resume_candidates(path, rank, device):
-        f = f"{path}.rank{rank}" if it is None else _gen_file(path, it, rank)
-        if _all_ranks(os.path.exists(f), device):
+        wrote = _agreed_world(path, it, rank, device, world)
+        if it is None or wrote == world:
+            need = [f"{path}.rank{rank}" if it is None else _gen_file(path, it, rank)]
+        else:       # written by a job of another size: this rank reads the files of ALL its ranks
+            need = [_gen_file(path, it, r) for r in range(wrote)]
+        if _all_ranks(all(os.path.exists(f) for f in need), device):
             return it
     return False
 
@@ -163,8 +201,20 @@ def load_resume(path: str, engine, loaders=(), rank: int = 0, generation: int | 
         generation = find_resume(path, rank, engine.device)
         if generation is False:
             raise FileNotFoundError(f"no complete resume generation under {path}")
-    fname = f"{path}.rank{rank}" if generation is None else _gen_file(path, generation, rank)
-    payload = torch.load(fname, map_location=engine.device, weights_only=False)
+    world = comm.world_size()
+    wrote = _agreed_world(path, generation, rank, engine.device, world)
+    shards = None
+    if generation is not None and wrote != world:
+        # A restart on another number of GPUs: every rank reads the files of all ranks of the job that wrote them (they
+        # have to be visible to it: one node, or a shared directory) and cuts its own optimizer slice out of them.
+        if not getattr(engine, "supports_resharded_resume", False):
+            raise RuntimeError(f"the resume files under {path} were written by {wrote} ranks and this job has {world}: "
+                               f"the {getattr(engine, 'name', 'this')} engine cannot re-shard them")
+        shards = [torch.load(_gen_file(path, generation, r), map_location="cpu", weights_only=False) for r in range(wrote)]
+        payload = shards[rank % wrote]
+    else:
+        fname = f"{path}.rank{rank}" if generation is None else _gen_file(path, generation, rank)
+        payload = torch.load(fname, map_location=engine.device, weights_only=False)
     key = torch.tensor([float(payload["iter"]), float(payload.get("step_count") or 0)], dtype=torch.float64,
                        device=engine.device)
     lo, hi = key.clone(), key.clone()
@@ -173,7 +223,12 @@ def load_resume(path: str, engine, loaders=(), rank: int = 0, generation: int | 
     if not torch.equal(lo, hi):
         raise RuntimeError(f"resume files under {path} disagree across ranks: iteration / optimizer step "
                            f"{lo.tolist()} .. {hi.tolist()}; refusing to resume from a mixed set")
-    engine.load_optimizer_state_dict(payload["optimizer"])
+    if shards is not None:
+        engine.load_optimizer_shards([sh["optimizer"] for sh in shards])
+        payload = dict(payload, loaders=shards[0]["loaders"])     # the sampling stream is shared by all ranks
+        del shards
+    else:
+        engine.load_optimizer_state_dict(payload["optimizer"])
     with torch.no_grad():
         bufs = dict(engine.module.named_buffers())
         for k, v in payload["buffers"].items():

@@ -334,11 +334,35 @@ class Engine(nn.Module):
                 "groups": [o.state_dict() for o in self.optims]}
 
     def load_optimizer_state_dict(self, sd):
-        assert sd["world"] == self.world, "resume with a different world size is not supported"
+        assert sd["world"] == self.world, ("this resume file was written by a job of another world size: "
+                                           "load_optimizer_shards() takes the files of all its ranks")
         self.step_count = sd["step"]
         for o, s in zip(self.optims, sd["groups"]):
             o.load_state_dict(s)
         with torch.no_grad():   # refresh the compute copies from the restored master weights
+            self._refresh_params_from_master()
+
+    supports_resharded_resume = True    # (the expert-parallel engines own different experts per world size: False)
+
+    def load_optimizer_shards(self, sds: list):
+        """Restore from the optimizer states of ALL ranks of a job that ran with another world size (a restart on
+        fewer or more GPUs). The flat groups are planned from the model alone, so a group's elements sit at the same
+        offsets whatever the world size; only the slice [lo, hi) a rank owns and the zero padding behind the last
+        parameter differ. Every element of this rank's slice is taken from the old shard that holds it."""
+        assert self.supports_resharded_resume, f"{self.name}: resume with a different world size is not supported"
+        assert len(sds) == sds[0]["world"] and all(len(s["groups"]) == len(self.optims) for s in sds), \
+            "the resume files do not belong to this model / engine layout"
+        self.step_count = sds[0]["step"]
+        with torch.no_grad():
+            for gi, o in enumerate(self.optims):
+                for name in ("master", "exp_avg", "exp_avg_sq"):
+                    dst = getattr(o, name)
+                    dst.zero_()                  # (elements no old shard covers are padding)
+                    for s in sds:
+                        og = s["groups"][gi]
+                        lo, hi = max(og["lo"], o.lo), min(og["hi"], o.hi)
+                        if hi > lo:
+                            dst[lo - o.lo:hi - o.lo].copy_(og[name][lo - og["lo"]:hi - og["lo"]])
             self._refresh_params_from_master()
 
     def _refresh_params_from_master(self):

@@ -295,6 +295,7 @@ class EPEngine(DDPEngine):
     over the same process group."""
 
     name = "ep"
+    supports_resharded_resume = False   # which experts a rank owns (and keeps optimizer state for) depends on the world size
 
     def _build_storage(self):
         self.dispatcher = ExpertParallelDispatcher(self.group, capacity=self.ep_capacity)
