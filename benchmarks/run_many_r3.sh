@@ -1,4 +1,4 @@
-# the benchmark configurations of BASELINE.md on one box (round 3): headline, MoE, 350M ZeRO-2, 1.3B (single at 48, FSDP at 16),
+# the benchmark configurations on one box: headline (GPT-2-124M), MoE 8x, 350M ZeRO-2, 1.3B (single at 48, FSDP at 16),
 # GQA + RoPE + SwiGLU, MoE at micro-batch 256, the wide latent-attention configuration
 set -o pipefail
 O=gpurun_out/many_r3.txt
