@@ -14,7 +14,7 @@ stored both as dataclass instances (like the reference) and as plain dicts
 ``save_resume`` / ``load_resume`` add what the reference lacks: optimizer state (per rank for
 sharded engines), iteration counter, RNG and data-loader state. A job restarted on ANOTHER number of
 ranks reads the files of all ranks of the job that wrote them and re-cuts the optimizer shards
-(data-parallel, ZeRO and fully sharded engines; the expert-parallel engines refuse).
+(every engine; the expert-parallel ones collect each routed expert from the old rank that owned it).
 """
 from __future__ import annotations
 

@@ -329,10 +329,6 @@ class Engine(nn.Module):
                 if k in sd and b is not None:
                     b.copy_(sd[k].to(b.device))
 
-    def optimizer_state_dict(self):
-        return {"step": self.step_count, "rank": self.rank, "world": self.world,
-                "groups": [o.state_dict() for o in self.optims]}
-
     def load_optimizer_state_dict(self, sd):
         assert sd["world"] == self.world, ("this resume file was written by a job of another world size: "
                                            "load_optimizer_shards() takes the files of all its ranks")
@@ -342,19 +338,36 @@ class Engine(nn.Module):
         with torch.no_grad():   # refresh the compute copies from the restored master weights
             self._refresh_params_from_master()
 
-    supports_resharded_resume = True    # (the expert-parallel engines own different experts per world size: False)
+    supports_resharded_resume = True
+
+    def _named_optimizer_group(self):
+        """(FlatGroup, FlatAdamW) of the one group whose CONTENT depends on the world size (the local routed experts of
+        the expert-parallel engines; always the last optimizer), or None. Such a group is saved with its slot names and
+        restored by name; every other group is restored by position."""
+        return None
+
+    def optimizer_state_dict(self):
+        sd = {"step": self.step_count, "rank": self.rank, "world": self.world,
+              "groups": [o.state_dict() for o in self.optims]}
+        named = self._named_optimizer_group()
+        if named is not None:
+            sd["named_slots"] = [(s.name, s.offset, s.numel) for s in named[0].slots]
+        return sd
 
     def load_optimizer_shards(self, sds: list):
         """Restore from the optimizer states of ALL ranks of a job that ran with another world size (a restart on
         fewer or more GPUs). The flat groups are planned from the model alone, so a group's elements sit at the same
         offsets whatever the world size; only the slice [lo, hi) a rank owns and the zero padding behind the last
-        parameter differ. Every element of this rank's slice is taken from the old shard that holds it."""
+        parameter differ. Every element of this rank's slice is taken from the old shard that holds it. The group of
+        local routed experts (expert-parallel engines) is restored tensor by tensor from whichever old rank owned it."""
         assert self.supports_resharded_resume, f"{self.name}: resume with a different world size is not supported"
         assert len(sds) == sds[0]["world"] and all(len(s["groups"]) == len(self.optims) for s in sds), \
             "the resume files do not belong to this model / engine layout"
         self.step_count = sds[0]["step"]
+        named = self._named_optimizer_group()
+        by_position = self.optims if named is None else self.optims[:-1]
         with torch.no_grad():
-            for gi, o in enumerate(self.optims):
+            for gi, o in enumerate(by_position):
                 for name in ("master", "exp_avg", "exp_avg_sq"):
                     dst = getattr(o, name)
                     dst.zero_()                  # (elements no old shard covers are padding)
@@ -363,6 +376,16 @@ class Engine(nn.Module):
                         lo, hi = max(og["lo"], o.lo), min(og["hi"], o.hi)
                         if hi > lo:
                             dst[lo - o.lo:hi - o.lo].copy_(og[name][lo - og["lo"]:hi - og["lo"]])
+            if named is not None:
+                group, optim = named
+                where = {nm: (s["groups"][-1], off, n) for s in sds for nm, off, n in s.get("named_slots", [])}
+                for slot in group.slots:
+                    if slot.name not in where:
+                        raise RuntimeError(f"the resume files hold no optimizer state for {slot.name}")
+                    og, off, n = where[slot.name]
+                    assert n == slot.numel, slot.name
+                    for name in ("master", "exp_avg", "exp_avg_sq"):
+                        getattr(optim, name)[slot.offset:slot.offset + slot.numel].copy_(og[name][off:off + n])
             self._refresh_params_from_master()
 
     def _refresh_params_from_master(self):

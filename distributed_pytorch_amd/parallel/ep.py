@@ -295,7 +295,10 @@ class EPEngine(DDPEngine):
     over the same process group."""
 
     name = "ep"
-    supports_resharded_resume = False   # which experts a rank owns (and keeps optimizer state for) depends on the world size
+
+    def _named_optimizer_group(self):
+        # which experts a rank owns (and keeps optimizer state for) depends on the world size
+        return (self.groups[-1], self.optims[-1]) if len(self.groups) > self._n_dense_groups else None
 
     def _build_storage(self):
         self.dispatcher = ExpertParallelDispatcher(self.group, capacity=self.ep_capacity)
@@ -424,6 +427,9 @@ class EPFSDPEngine(FSDPEngine):
     the all-to-all dispatcher and are never reduced (their gradient is already the global sum)."""
 
     name = "ep_fsdp"
+
+    def _named_optimizer_group(self):
+        return (self.expert_group, self.expert_optim) if self.expert_group is not None else None
 
     def _build_storage(self):
         self.dispatcher = ExpertParallelDispatcher(self.group, capacity=self.ep_capacity)

@@ -102,29 +102,48 @@ def test_resume_on_another_world_size(tmp_path, mode, wrote, reads):
     assert m["iter"] == 3 and m["world"] == reads and m["prev"] == 2 and m["prev_world"] == wrote
 
 
-def _ep_reader(rank, world, root):
-    from distributed_pytorch_amd.parallel.ep import EPEngine
+MOE = {**CFG, "moe": True, "n_exp": 5, "n_shared": 1, "n_act": 2}     # four routed experts: 4, 2 or 1 per rank
+
+
+def _ep_engine(kind):
+    from distributed_pytorch_amd.parallel.ep import EPEngine, EPFSDPEngine
     torch.manual_seed(0)
-    cfg = LLMconfig(**{**CFG, "moe": True, "n_exp": 3, "n_shared": 1, "n_act": 2}).finalize()
-    eng = EPEngine(LLM(cfg), weight_decay=0.1, dtype="fp32", bucket_mb=0.01)
-    try:
-        load_resume(os.path.join(root, "run_resume"), eng, (), rank)
-    except RuntimeError as e:
-        return "cannot re-shard" in str(e)
-    return False
+    cls = EPEngine if kind == "ep" else EPFSDPEngine
+    return cls(LLM(LLMconfig(**MOE).finalize()), weight_decay=0.1, dtype="fp32", bucket_mb=0.01)
 
 
-def _ep_writer(rank, world, root):
-    from distributed_pytorch_amd.parallel.ep import EPEngine
-    torch.manual_seed(0)
-    cfg = LLMconfig(**{**CFG, "moe": True, "n_exp": 3, "n_shared": 1, "n_act": 2}).finalize()
-    eng = EPEngine(LLM(cfg), weight_decay=0.1, dtype="fp32", bucket_mb=0.01)
-    save_resume(os.path.join(root, "run_resume"), eng, 0, (), rank, world)
-    return True
+def _ep_writer(rank, world, root, kind):
+    path = os.path.join(root, "run_resume")
+    eng = _ep_engine(kind)
+    for it in range(3):
+        _step(eng, rank, world, it)
+    save_resume(path, eng, 2, (), rank, world)
+    sd = eng.state_dict()
+    if rank == 0:
+        torch.save({"sd": sd, "step": eng.step_count}, os.path.join(root, "truth.pt"))
+    return _step(eng, rank, world, 3)
 
 
-def test_expert_parallel_refuses_another_world_size(tmp_path):
-    """Which experts a rank owns depends on the world size: the expert-parallel engines say so instead of loading."""
+def _ep_reader(rank, world, root, kind):
+    path = os.path.join(root, "run_resume")
+    eng = _ep_engine(kind)
+    assert load_resume(path, eng, (), rank) == 2
+    truth = torch.load(os.path.join(root, "truth.pt"), weights_only=False)
+    assert eng.step_count == truth["step"]
+    sd = eng.state_dict()
+    for k, v in truth["sd"].items():
+        assert torch.equal(sd[k].cpu(), v.cpu()), k
+    return _step(eng, rank, world, 3)
+
+
+@pytest.mark.parametrize("kind,wrote,reads", [("ep", 2, 1), ("ep", 1, 2), ("ep", 2, 4), ("ep_fsdp", 2, 1), ("ep_fsdp", 1, 2)])
+def test_expert_parallel_resume_on_another_world_size(tmp_path, kind, wrote, reads):
+    """The routed experts change owners with the world size: their optimizer state is saved with the parameter names
+    and every new rank collects its experts' weights and moments from whichever old rank held them; the dense part is
+    re-cut by position like in the other engines. Equal gathered weights, and the repeated step gives the same loss
+    (the experts' second moments enter it through the update that precedes it)."""
     root = str(tmp_path)
-    assert all(run_distributed(_ep_writer, 2, root))
-    assert all(run_distributed(_ep_reader, 1, root))
+    before = run_distributed(_ep_writer, wrote, root, kind)
+    after = run_distributed(_ep_reader, reads, root, kind)
+    # (the load-balancing term is a function of each rank's own tokens, so the mean over ranks moves by ~1e-4 with the split)
+    assert abs(sum(before) / len(before) - sum(after) / len(after)) < 1e-3
