@@ -117,34 +117,68 @@ def _agreed_marker(path: str, rank: int, device):
     return latest, (prev if prev != _NONE else None)
 
 
-def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None,
-                loader_states=None):
-    """Resume point of iteration ``it`` as one file per rank (optimizer shards are rank-local), committed
-    as a set: rank 0 reads the current marker and every rank receives it (before anything changes), every rank
-    writes ``<path>.it<it>.rank<r>``, all ranks meet at a barrier, and only then rank 0 atomically replaces the
-    marker ``<path>.latest`` = {iter, prev, world}. A job that dies while some ranks are still writing leaves
-    the marker on the previous, complete generation, which is kept until the new one is committed; the
-    generation before that is deleted afterwards, by every rank from the SAME agreed marker (a rank that
-    re-read the file after the barrier could already see the new marker and would keep its old shard forever)."""
+_PINNED: dict = {}       # staging buffers of the background writer, by position in the state (reused by every save)
+
+
+def _to_host(obj, where: str = ""):
+    """A copy of a (nested) state with every tensor on the host: a snapshot the training loop can no longer change.
+    Device tensors go through pinned staging buffers that are allocated once and reused by every later snapshot (a
+    pageable copy runs at a tenth of the rate: 1.5 s instead of 0.2 s for 4 GB); the caller makes sure that the
+    previous snapshot's writer has finished before it takes the next one."""
+    if torch.is_tensor(obj):
+        if obj.device.type != "cuda":
+            return obj.detach().clone()
+        buf = _PINNED.get(where)
+        if buf is None or buf.shape != obj.shape or buf.dtype != obj.dtype:
+            buf = _PINNED[where] = torch.empty(obj.shape, dtype=obj.dtype, device="cpu", pin_memory=True)
+        buf.copy_(obj.detach(), non_blocking=True)
+        return buf
+    if isinstance(obj, dict):
+        return {k: _to_host(v, f"{where}/{k}") for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_host(v, f"{where}/{i}") for i, v in enumerate(obj))
+    return obj
+
+
+class _PendingSave:
+    """A generation whose file is being written by a background thread and is not committed yet."""
+
+    def __init__(self, path, it, rank, world, old, old_worlds, thread, error):
+        self.path, self.it, self.rank, self.world = path, it, rank, world
+        self.old, self.old_worlds, self.thread, self.error = old, old_worlds, thread, error
+
+
+_PENDING: list = []      # at most one entry: the generation in flight of this process
+
+
+def finish_pending_save() -> int | None:
+    """Wait for the background write of the generation in flight (if any) and commit it: barrier, marker, barrier,
+    removal of the generation that aged out. Collective (every rank has the same generation in flight); called by the
+    next ``save_resume`` and at the end of training. Returns the committed iteration."""
+    if not _PENDING:
+        return None
+    p = _PENDING.pop()
+    p.thread.join()
+    if p.error:
+        raise RuntimeError(f"writing the resume file of iteration {p.it} failed: {p.error[0]}")
+    _commit(p.path, p.it, p.rank, p.world, p.old, p.old_worlds)
+    return p.it
+
+
+def poll_pending_save(device) -> int | None:
+    """Commit the generation in flight as soon as EVERY rank's writer has finished: one tiny all-reduce per call while
+    a save is pending (nothing otherwise), so the training loop calls it once per step and the new generation becomes
+    the resume point within a step of its last file being complete. Collective. Returns the committed iteration."""
+    if not _PENDING:
+        return None
+    done = not _PENDING[0].thread.is_alive()
+    if not _all_ranks(done, device):
+        return None
+    return finish_pending_save()
+
+
+def _commit(path, it, rank, world, old, old_worlds):
     import json
-    Path(path).parent.mkdir(parents=True, exist_ok=True)
-    device = getattr(engine, "device", torch.device("cpu"))
-    old = _agreed_marker(path, rank, device)
-    old_worlds = _marker_worlds(path) if rank == 0 else {}
-    payload = {
-        "iter": it,
-        "world": world,
-        "step_count": getattr(engine, "step_count", None),
-        "optimizer": engine.optimizer_state_dict(),
-        "buffers": {k: v.detach().cpu() for k, v in engine.module.named_buffers() if v is not None},
-        "torch_rng": torch.get_rng_state(),
-        "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
-        "loaders": loader_states if loader_states is not None else [l.state_dict() for l in loaders],
-        "extra": extra or {},
-    }
-    mine = _gen_file(path, it, rank)
-    torch.save(payload, mine + ".tmp")
-    os.replace(mine + ".tmp", mine)
     comm.barrier()                      # every rank's file of this generation is complete
     prev = old[0] if old is not None and old[0] != it else (old[1] if old is not None else None)
     if rank == 0:
@@ -161,6 +195,64 @@ def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: in
                     os.remove(_gen_file(path, stale, r))
                 except OSError:
                     pass
+
+
+def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None,
+                loader_states=None, background: bool = False):
+    """Resume point of iteration ``it`` as one file per rank (optimizer shards are rank-local), committed
+    as a set: rank 0 reads the current marker and every rank receives it (before anything changes), every rank
+    writes ``<path>.it<it>.rank<r>``, all ranks meet at a barrier, and only then rank 0 atomically replaces the
+    marker ``<path>.latest`` = {iter, prev, world}. A job that dies while some ranks are still writing leaves
+    the marker on the previous, complete generation, which is kept until the new one is committed; the
+    generation before that is deleted afterwards, by every rank from the SAME agreed marker (a rank that
+    re-read the file after the barrier could already see the new marker and would keep its old shard forever).
+
+    ``background``: the state is snapshotted to host memory here (a device-to-host copy, the only part the training
+    loop waits for), a thread serialises and writes it while training goes on, and the commit (the collectives above)
+    happens in ``poll_pending_save()`` (called by the training loop every step: as soon as every rank's file is
+    complete), at the latest at the next call or in ``finish_pending_save()``: until then the marker keeps naming the
+    previous generation, so a job that dies in between resumes from that one."""
+    finish_pending_save()               # at most one generation in flight
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    device = getattr(engine, "device", torch.device("cpu"))
+    old = _agreed_marker(path, rank, device)
+    old_worlds = _marker_worlds(path) if rank == 0 else {}
+    payload = {
+        "iter": it,
+        "world": world,
+        "step_count": getattr(engine, "step_count", None),
+        "optimizer": engine.optimizer_state_dict(),
+        "buffers": {k: v.detach().cpu() for k, v in engine.module.named_buffers() if v is not None},
+        "torch_rng": torch.get_rng_state(),
+        "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
+        "loaders": loader_states if loader_states is not None else [l.state_dict() for l in loaders],
+        "extra": extra or {},
+    }
+    mine = _gen_file(path, it, rank)
+
+    def write(state):
+        torch.save(state, mine + ".tmp")
+        os.replace(mine + ".tmp", mine)
+
+    if background:
+        import threading
+        snapshot = _to_host(payload)    # (tensors of the live optimizer state would change under the writer)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()    # the staged copies are complete before the optimizer runs again
+        error: list = []
+
+        def run():
+            try:
+                write(snapshot)
+            except Exception as e:      # noqa: BLE001 - reported by the commit on the main thread
+                error.append(repr(e))
+
+        t = threading.Thread(target=run, name=f"resume-writer-it{it}", daemon=False)
+        t.start()
+        _PENDING.append(_PendingSave(path, it, rank, world, old, old_worlds, t, error))
+        return
+    write(payload)
+    _commit(path, it, rank, world, old, old_worlds)
 
 
 def resume_candidates(path: str, rank: int = 0, device=None) -> list[int | None]:

@@ -114,6 +114,7 @@ class Trainconfig:
     seed: int = 1729
     resume: str = ""                  # resume checkpoint written with --save_interval; "auto" = this run's own, if present
     save_interval: int = 0
+    save_async: bool = False          # resume files are written by a background thread and committed at the next save point
     metrics_jsonl: str = ""
     profile: str = ""                 # "" off | events (no synchronisation) | sync | kernels (per-kernel table)
     log_interval: int = 1
@@ -249,6 +250,8 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--seed", type=int, default=tc.seed)
     p.add_argument("--resume", type=str, default=tc.resume)
     p.add_argument("--save_interval", type=int, default=tc.save_interval)
+    p.add_argument("--save_async", action="store_true", default=tc.save_async,
+                   help="write the periodic resume files in the background (snapshot to host memory, commit at the next save point)")
     p.add_argument("--metrics_jsonl", type=str, default=tc.metrics_jsonl)
     p.add_argument("--profile", type=str, nargs="?", const="events", default=tc.profile,
                    choices=["", "events", "sync", "kernels"],

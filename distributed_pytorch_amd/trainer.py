@@ -22,7 +22,7 @@ from time import perf_counter
 
 import torch
 
-from .checkpoint import load_resume, save_reference_checkpoint, save_resume
+from .checkpoint import finish_pending_save, load_resume, poll_pending_save, save_reference_checkpoint, save_resume
 from .config import LLMconfig, Trainconfig
 from .data import DataLoader, check_vocab, ensure_synthetic, resolve_data_dir
 from .models.llm import LLM
@@ -250,10 +250,12 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
                 f"tok/s: {tokens_per_s:,.0f} | MFU: {100 * util:.2f}%")
         sink.write(step=it, loss=last_loss, dt_ms=1000 * dt, tokens_per_s=tokens_per_s, mfu=util, lr=lr,
                    mem_gb=mem / 1024 ** 3, peak_flops=PEAK_BF16_DENSE_FLOPS)
+        poll_pending_save(device)   # (--save_async: commits the generation in flight once every rank has written it)
         if tc.save_interval and it > 0 and it % tc.save_interval == 0:
             save_resume(tc.file_name + "_resume", engine, it, (train_loader, val_loader), info.rank, info.world_size,
-                        loader_states=[loader_state, val_loader.state_dict()])
+                        loader_states=[loader_state, val_loader.state_dict()], background=getattr(tc, "save_async", False))
 
+    finish_pending_save()       # (--save_async: the last generation's write and commit)
     if tc.profile and master:
         print(timer.report(), flush=True)
         if ktable.table:

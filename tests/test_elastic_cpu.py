@@ -4,10 +4,15 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_ddp_job_survives_a_dead_rank(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--save_async"]])
+def test_ddp_job_survives_a_dead_rank(tmp_path, extra):
+    """(--save_async: the generation of iteration 5 is written by a background thread and committed by the loop's poll
+    once both ranks' files are complete, a step later: the rank that dies at 7 finds it committed.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", DPA_FAULT_AT_ITER="7", MASTER_ADDR="127.0.0.1",
                GLOO_SOCKET_IFNAME="lo")
@@ -17,13 +22,16 @@ def test_ddp_job_survives_a_dead_rank(tmp_path):
            *("--dataset synthetic --synthetic_tokens 65536 --vocab_size 256 --block_size 32 --n_embd 64 --n_layer 2 "
              "--n_head 4 --up_dim 96 --attn mha --pos_emb learn --non_linearity gelu --batch_size 2 "
              "--total_batch_size_str 2*32*2 --max_iters 10 --save_interval 5 --resume auto").split(),
-           "--data_dir", str(tmp_path / "data"), "--file_name", str(tmp_path / "run")]
+           "--data_dir", str(tmp_path / "data"), "--file_name", str(tmp_path / "run"), *extra]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert "[fault injection] rank 1 exits at iteration 7" in out
     assert "resumed from" in out and "at iteration 6" in out, out[-3000:]
     assert any(ln.startswith("step: 10 ") for ln in r.stdout.splitlines()), out[-3000:]
+    import json
+    m = json.load(open(tmp_path / "run_resume.latest"))
+    assert m["iter"] == 10                      # the last generation is committed before the job ends, in both modes
 
 
 def test_fsdp_job_continues_on_fewer_ranks(tmp_path):

@@ -449,3 +449,46 @@ def test_training_trajectory_bf16_hip_follows_fp32_cpu_engine(name):
     for s in range(0, steps, 5):
         a, b = sum(want[s:s + 5]) / 5, sum(got[s:s + 5]) / 5
         assert abs(a - b) < 0.05 * a + 0.02, f"{name}: steps {s}-{s + 4}: fp32 {a:.4f}, bf16 HIP {b:.4f}\n{want}\n{got}"
+
+
+@pytest.mark.gpu
+def test_background_resume_snapshot_on_the_gpu(tmp_path):
+    """--save_async on the GPU: the snapshot goes through pinned staging buffers (reused by the next save), the writer
+    thread serialises it while the optimizer moves on, and what loads back is the state at the call."""
+    from distributed_pytorch_amd import checkpoint as ck
+    from distributed_pytorch_amd.config import LLMconfig
+    from distributed_pytorch_amd.models.llm import LLM
+    from distributed_pytorch_amd.parallel.engine import Engine
+    cfg = LLMconfig(vocab_size=1024, block_size=128, n_embd=256, n_layer=2, n_head=4, up_dim=512, attn="mha", pos_emb="learn",
+                    non_linearity="gelu").finalize()
+
+    def make():
+        torch.manual_seed(0)
+        return Engine(LLM(cfg), device="cuda:0", dtype="bf16")
+
+    def step(eng, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randint(0, cfg.vocab_size, (4, 128), generator=g).cuda()
+        eng.zero_grad()
+        _, loss, _ = eng(x, x.roll(-1, 1))
+        loss.backward()
+        eng.clip_grad_norm_(1.0)
+        eng.step(1e-3)
+
+    path = str(tmp_path / "run_resume")
+    eng = make()
+    truth = {}
+    for it in range(3):
+        step(eng, it)
+        truth[it] = [(o.master.clone(), o.exp_avg_sq.clone()) for o in eng.optims]
+        ck.save_resume(path, eng, it, (), 0, 1, background=True)
+        staged = {k: v.data_ptr() for k, v in ck._PINNED.items()}
+        if it:
+            assert staged == first_staged           # the staging buffers of the first snapshot serve every later one
+        first_staged = staged
+    step(eng, 3)                                    # the live state moves past the last snapshot before its commit
+    assert ck.finish_pending_save() == 2
+    fresh = make()
+    assert ck.load_resume(path, fresh, (), 0) == 2
+    for o, (m, v) in zip(fresh.optims, truth[2]):
+        assert torch.equal(o.master, m) and torch.equal(o.exp_avg_sq, v)

@@ -130,3 +130,34 @@ def _worker_agreed(rank, world, root, layout):
 @pytest.mark.parametrize("layout", ["shared", "node_local"])
 def test_marker_is_read_by_rank0_only_and_old_generations_go_on_every_rank(tmp_path, layout):
     assert all(run_distributed(_worker_agreed, 2, str(tmp_path), layout))
+
+
+def _async_worker(rank, world, root, mode):
+    """Background writing: the snapshot is the state at the call, the commit comes with the next call (or the final
+    flush), and until then the marker names the previous generation."""
+    from distributed_pytorch_amd import checkpoint as ck
+    path = os.path.join(root, "run_resume")
+    eng = _engine(mode)
+    _step(eng, rank, 0)
+    save_resume(path, eng, 0, (), rank, world, background=True)
+    assert len(ck._PENDING) == 1 and _read_marker(path) is None          # written in the background, not committed
+    _step(eng, rank, 1)                                                    # training goes on and changes the live state
+    truth1 = [o.exp_avg_sq.clone() for o in eng.optims]
+    save_resume(path, eng, 1, (), rank, world, background=True)            # commits generation 0, starts generation 1
+    torch.distributed.barrier()
+    assert _read_marker(path) == (0, None)
+    _step(eng, rank, 2)                                                    # the live state moves on past the snapshot
+    assert find_resume(path, rank, eng.device) == 0                        # a job dying here resumes from generation 0
+    assert ck.finish_pending_save() == 1
+    torch.distributed.barrier()
+    assert _read_marker(path) == (1, 0) and ck.finish_pending_save() is None
+    fresh = _engine(mode)
+    assert load_resume(path, fresh, (), rank) == 1
+    for o, t in zip(fresh.optims, truth1):
+        assert torch.equal(o.exp_avg_sq, t)                                # the snapshot, not the state two steps later
+    return True
+
+
+@pytest.mark.parametrize("mode", ["ddp", "zero2"])
+def test_background_save_snapshots_and_commits_late(tmp_path, mode):
+    assert all(run_distributed(_async_worker, 2, str(tmp_path), mode))
