@@ -11,7 +11,7 @@ port=29680
 dense="--preset char-10m --dataset synthetic --synthetic_tokens 524288 --batch_size 2 --total_batch_size_str 2*256*8*2"
 moe="--dataset synthetic --synthetic_tokens 524288 --vocab_size 1024 --block_size 256 --n_embd 256 --n_layer 2 --n_head 4 --up_dim 512
      --attn mha --pos_emb learn --non_linearity swiglu --moe --n_exp 9 --n_shared 1 --n_act 2 --batch_size 2 --total_batch_size_str 2*256*8"
-common="--max_iters 12 --eval --eval_interval 6 --eval_iters 2 --warmup_steps 2 --save_model --save_interval 4 --resume auto"
+common="--max_iters 12 --eval --eval_interval 6 --eval_iters 2 --warmup_steps 2 --save_model --save_interval 4 --resume auto ${SAVE_ASYNC:+--save_async}"
 fail=0
 run() {   # entry, model flags...
   entry=$1; shift
