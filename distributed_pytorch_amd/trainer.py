@@ -145,6 +145,11 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
         from .checkpoint import find_resume
         resume_path = cand if find_resume(cand, info.rank, device) is not False else ""
         say(f"--resume auto: {'found ' + cand if resume_path else 'no resume files, starting fresh'}")
+        if not resume_path and master and os.path.exists(cand + ".latest"):
+            # a marker without a complete generation: files deleted, or written by a job of another size whose ranks'
+            # files are not all visible from here (node-local directories): say so instead of silently starting over
+            say(f"warning: {cand}.latest exists but no generation it names is complete on every rank "
+                f"(a restart on another number of ranks reads the files of ALL ranks of the job that wrote them)")
     if resume_path:
         start_iter = load_resume(resume_path, engine, (train_loader, val_loader), info.rank) + 1
         say(f"resumed from {resume_path} at iteration {start_iter}")
