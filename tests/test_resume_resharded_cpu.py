@@ -89,8 +89,7 @@ def _reader(rank, world, root, mode, wrote):
     return loss
 
 
-@pytest.mark.parametrize("mode,wrote,reads", [("zero2", 2, 1), ("zero2", 1, 2), ("zero2", 2, 4), ("fsdp", 2, 1), ("fsdp", 1, 2),
-                                              ("ddp", 2, 1)])
+@pytest.mark.parametrize("mode,wrote,reads", [("zero2", 1, 2), ("zero2", 2, 4), ("fsdp", 2, 1), ("ddp", 2, 1)])
 def test_resume_on_another_world_size(tmp_path, mode, wrote, reads):
     root = str(tmp_path)
     before = run_distributed(_writer, wrote, root, mode)
@@ -136,7 +135,7 @@ def _ep_reader(rank, world, root, kind):
     return _step(eng, rank, world, 3)
 
 
-@pytest.mark.parametrize("kind,wrote,reads", [("ep", 2, 1), ("ep", 1, 2), ("ep", 2, 4), ("ep_fsdp", 2, 1), ("ep_fsdp", 1, 2)])
+@pytest.mark.parametrize("kind,wrote,reads", [("ep", 2, 1), ("ep", 2, 4), ("ep_fsdp", 1, 2)])
 def test_expert_parallel_resume_on_another_world_size(tmp_path, kind, wrote, reads):
     """The routed experts change owners with the world size: their optimizer state is saved with the parameter names
     and every new rank collects its experts' weights and moments from whichever old rank held them; the dense part is
