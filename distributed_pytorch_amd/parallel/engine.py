@@ -25,7 +25,6 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .. import ops
 from . import comm
 from .flat import FlatAdamW, FlatGroup, plan_groups
 

@@ -33,13 +33,12 @@ from __future__ import annotations
 from collections import OrderedDict
 
 import torch
-import torch.distributed as dist
 
 from .. import ops
 from . import comm
 from .ddp import DDPEngine
 from .fsdp import FSDPEngine
-from .flat import FlatAdamW, FlatGroup, plan_groups, unique_named_parameters
+from .flat import FlatAdamW, FlatGroup, unique_named_parameters
 
 
 class _WaitGrad(torch.autograd.Function):
