@@ -15,7 +15,7 @@ from __future__ import annotations
 import argparse
 import ast
 import operator
-from dataclasses import asdict, dataclass, field, fields
+from dataclasses import asdict, dataclass, fields
 from typing import Optional
 
 __all__ = ["LLMconfig", "Trainconfig", "safe_int_expr", "build_parser", "configs_from_args", "default_configs",

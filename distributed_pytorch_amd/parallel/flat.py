@@ -26,7 +26,6 @@ when a group is sharded (the reference's FSDP path decides on flattened 1-D view
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Iterable, Sequence
 
