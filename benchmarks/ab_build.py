@@ -24,7 +24,7 @@ def main():
     obj = out_dir / f"{Path(src).stem}_{name}.o"
     hipcc = B._hipcc()
     common = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={B.ARCH}", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
-              f"-I{B.CSRC}", "-Wno-unused-result"]
+              f"-I{B.CSRC}", "-Wno-unused-result", "-Wno-inline-asm"]
     subprocess.run([hipcc, *common, *B.EXTRA_FLAGS.get(src, []), *flags, "-c", str(B.CSRC / src), "-o", str(obj)], check=True)
     stems = [f.stem for f in [*sorted(B.CSRC.glob("*.hip")), *sorted(B.CSRC.glob("*.cpp")), *sorted((B.CSRC / "comm").glob("*.cpp"))]]
     objs = [obj if st == Path(src).stem else B.OBJ / (st + ".o") for st in stems]
