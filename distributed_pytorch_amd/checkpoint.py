@@ -195,6 +195,17 @@ def _commit(path, it, rank, world, old, old_worlds):
                     os.remove(_gen_file(path, stale, r))
                 except OSError:
                     pass
+    # This rank's files of generations the marker never named: written by a job that died before their commit (and
+    # whose relaunch did not happen to save at the same iteration again). Nothing can resume from them.
+    import glob
+    import re
+    for f in glob.glob(f"{glob.escape(path)}.it*.rank{rank}"):
+        m = re.fullmatch(r"\.it(\d+)\.rank\d+", f[len(path):])
+        if m and int(m.group(1)) not in (it, prev):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
 
 def save_resume(path: str, engine, it: int, loaders=(), rank: int = 0, world: int = 1, extra=None,

@@ -161,3 +161,21 @@ def _async_worker(rank, world, root, mode):
 @pytest.mark.parametrize("mode", ["ddp", "zero2"])
 def test_background_save_snapshots_and_commits_late(tmp_path, mode):
     assert all(run_distributed(_async_worker, 2, str(tmp_path), mode))
+
+
+def _orphan_worker(rank, world, root):
+    """A generation written but never committed (its job died before the marker moved) is removed by the next commit."""
+    path = os.path.join(root, "run_resume")
+    eng = _engine("zero2")
+    _step(eng, rank, 0)
+    save_resume(path, eng, 0, (), rank, world)
+    torch.save({"junk": True}, _gen_file(path, 7, rank))        # what a job that died mid-save leaves behind
+    _step(eng, rank, 1)
+    save_resume(path, eng, 1, (), rank, world)
+    torch.distributed.barrier()
+    left = sorted(f for f in os.listdir(root) if f.startswith("run_resume.it") and f.endswith(f".rank{rank}"))
+    return left == [f"run_resume.it0.rank{rank}", f"run_resume.it1.rank{rank}"]
+
+
+def test_uncommitted_generations_are_cleared(tmp_path):
+    assert all(run_distributed(_orphan_worker, 2, str(tmp_path)))
