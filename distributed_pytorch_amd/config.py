@@ -233,31 +233,39 @@ def build_parser(tc: Trainconfig | None = None, mc: LLMconfig | None = None) -> 
     p.add_argument("--preset", type=str, default="", choices=[""] + sorted(PRESETS),
                    help="named model shape; explicit model flags still override it")
     p.add_argument("--weight_decay", type=float, default=tc.weight_decay)
-    p.add_argument("--dtype", type=str, default=tc.dtype, choices=["auto", "bf16", "fp32"])
-    p.add_argument("--grad_dtype", type=str, default=tc.grad_dtype, choices=["auto", "bf16", "fp32"])
-    p.add_argument("--bucket_mb", type=float, default=tc.bucket_mb)
-    p.add_argument("--fsdp_prefetch", type=int, default=tc.fsdp_prefetch)
-    p.add_argument("--fsdp_inflight", type=int, default=tc.fsdp_inflight)
-    p.add_argument("--rccl_max_channels", type=int, default=tc.rccl_max_channels)
-    p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels)
-    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high"])
-    p.add_argument("--vocab_parallel", action="store_true", default=tc.vocab_parallel)
-    p.add_argument("--ep_capacity", type=float, default=tc.ep_capacity)
-    p.add_argument("--tied_tail", type=str, default=tc.tied_tail, choices=["fused", "split"])
-    p.add_argument("--comm_backend", type=str, default=tc.comm_backend, choices=["c10d", "own"])
-    p.add_argument("--data_dir", type=str, default=tc.data_dir)
-    p.add_argument("--synthetic_tokens", type=str, default=str(tc.synthetic_tokens))
+    p.add_argument("--dtype", type=str, default=tc.dtype, choices=["auto", "bf16", "fp32"],
+                   help="compute dtype of the parameters and activations (auto: bf16 on the GPU, fp32 on the CPU); the optimizer keeps fp32 master weights")
+    p.add_argument("--grad_dtype", type=str, default=tc.grad_dtype, choices=["auto", "bf16", "fp32"],
+                   help="dtype of the flat gradient buffers and of the gradient collectives")
+    p.add_argument("--bucket_mb", type=float, default=tc.bucket_mb, help="size of a gradient bucket (one collective) in MiB")
+    p.add_argument("--fsdp_prefetch", type=int, default=tc.fsdp_prefetch, help="FSDP: units all-gathered ahead of the running block")
+    p.add_argument("--fsdp_inflight", type=int, default=tc.fsdp_inflight, help="FSDP: reduce-scatters in flight before backward waits")
+    p.add_argument("--rccl_max_channels", type=int, default=tc.rccl_max_channels, help="upper bound on RCCL channels, i.e. CUs a collective takes (0: RCCL decides)")
+    p.add_argument("--rccl_min_channels", type=int, default=tc.rccl_min_channels, help="lower bound on RCCL channels (0: RCCL decides)")
+    p.add_argument("--comm_priority", type=str, default=tc.comm_priority, choices=["default", "high"],
+                   help="priority of the HIP stream the collectives run on (high: c10d transport only)")
+    p.add_argument("--vocab_parallel", action="store_true", default=tc.vocab_parallel,
+                   help="split the head's vocabulary over the ranks (pays below vocabulary / ranks tokens per rank and step)")
+    p.add_argument("--ep_capacity", type=float, default=tc.ep_capacity,
+                   help="expert parallel: static per-peer capacity factor, no host read per layer, overflow pairs dropped (0: exact variable all-to-all)")
+    p.add_argument("--tied_tail", type=str, default=tc.tied_tail, choices=["fused", "split"],
+                   help="DDP: reduce the tied embedding / head gradient as one tensor at the end of backward, or the head's part early")
+    p.add_argument("--comm_backend", type=str, default=tc.comm_backend, choices=["c10d", "own"],
+                   help="GPU transport: torch.distributed's RCCL process group, or the framework's own RCCL communicator")
+    p.add_argument("--data_dir", type=str, default=tc.data_dir, help="directory of train.bin / val.bin (default: data/<dataset>)")
+    p.add_argument("--synthetic_tokens", type=str, default=str(tc.synthetic_tokens), help="--dataset synthetic: tokens to generate (an arithmetic expression is accepted)")
     p.add_argument("--seed", type=int, default=tc.seed)
-    p.add_argument("--resume", type=str, default=tc.resume)
-    p.add_argument("--save_interval", type=int, default=tc.save_interval)
+    p.add_argument("--resume", type=str, default=tc.resume,
+                   help="path prefix of resume files to continue from, or 'auto': this run's own files if a complete generation exists (the job may have another number of ranks than the one that wrote them)")
+    p.add_argument("--save_interval", type=int, default=tc.save_interval, help="write resume files (optimizer shards, RNG, loader state) every N iterations (0: never)")
     p.add_argument("--save_async", action="store_true", default=tc.save_async,
-                   help="write the periodic resume files in the background (snapshot to host memory, commit at the next save point)")
-    p.add_argument("--metrics_jsonl", type=str, default=tc.metrics_jsonl)
+                   help="write the periodic resume files in the background (snapshot to pinned host memory, committed once every rank's file is complete)")
+    p.add_argument("--metrics_jsonl", type=str, default=tc.metrics_jsonl, help="append one JSON record per step (loss, step time, tokens/s, MFU, lr, memory) to this file")
     p.add_argument("--profile", type=str, nargs="?", const="events", default=tc.profile,
                    choices=["", "events", "sync", "kernels"],
                    help="phase timing from stream events (default), synchronised wall clock, or a per-kernel table")
-    p.add_argument("--log_interval", type=int, default=tc.log_interval)
-    p.add_argument("--sync_loss_every", type=int, default=tc.sync_loss_every)
+    p.add_argument("--log_interval", type=int, default=tc.log_interval, help="print the step line every N iterations")
+    p.add_argument("--sync_loss_every", type=int, default=tc.sync_loss_every, help="read the loss back to the host every N steps (each read drains the GPU queue)")
     p.add_argument("--hip_graph", type=str, nargs="?", const="on", default=tc.hip_graph, choices=["auto", "on", "off"],
                    help="replay the whole optimizer step from one hipGraph (single GPU); auto = launch-bound steps only")
     return p
