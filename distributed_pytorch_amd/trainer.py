@@ -182,6 +182,7 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
     # Fault injection for restart drills: DPA_FAULT_AT_ITER=<n> makes the last rank die once at iteration n
     # (a marker file keeps the relaunched job from dying again).
     fault_at = int(os.environ.get("DPA_FAULT_AT_ITER", "-1"))
+    win_t0, win_n, dt = None, 0, float("nan")     # timing window since the last host <- device synchronisation
     for it in range(start_iter, tc.max_iters + 1):
         if it == fault_at and info.rank == info.world_size - 1:
             marker = tc.file_name + "_fault_injected"
@@ -204,7 +205,10 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
             say(f"--------val run-------- train loss {losses['train']:.4f} | val loss {losses['val']:.4f} | "
                 f"dt {1000 * (b - a):.4f}ms")
             t0 = b
+            win_t0, win_n = None, 0     # (the evaluation drained the device: the timing window starts over)
 
+        if win_t0 is None:
+            win_t0 = t0
         ktable.step_begin()
         if graphed is not None:
             batches = [(x, y)]
@@ -246,7 +250,14 @@ def train(tc: Trainconfig, mc: LLMconfig, mode: str = "single") -> dict:
             if read_loss:
                 torch.cuda.synchronize()
             mem = torch.cuda.memory_reserved()
-        dt = perf_counter() - t0
+        # Step time: wall clock since the last point at which the device was drained, per step of that window. With
+        # --sync_loss_every 1 (the reference's behaviour) that is this step's own wall time; with N > 1 the steps in
+        # between only enqueue work (microseconds of wall time) and the N-th one waits for all of them, so neither is
+        # a step time by itself: the window's average is, and the steps in between repeat the last measured value.
+        win_n += 1
+        if read_loss or device.type != "cuda":
+            dt = (perf_counter() - win_t0) / win_n
+            win_t0, win_n = None, 0
         tokens_per_s = tc.total_batch_size / dt
         util = mfu(tokens_per_s, flops_tok, info.world_size)
         if it % max(tc.log_interval, 1) == 0:
