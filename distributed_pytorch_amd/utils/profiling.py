@@ -93,6 +93,8 @@ class PhaseTimer:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
                 self._pending.append((name, e0, e1))
+                if len(self._pending) >= 256:
+                    self._drain_finished()
             else:
                 if cuda:
                     torch.cuda.synchronize()
@@ -101,6 +103,17 @@ class PhaseTimer:
             self.bytes[name] += nbytes
             if lib:
                 lib.roctxRangePop()
+
+    def _drain_finished(self):
+        """Fold the event pairs that have completed into the totals without waiting for the others: a long profiled run
+        then holds a few hundred events at any time instead of twenty more per step."""
+        keep = []
+        for name, e0, e1 in self._pending:
+            if e1.query():
+                self.tot[name] += e0.elapsed_time(e1) * 1e-3
+            else:
+                keep.append((name, e0, e1))
+        self._pending = keep
 
     def _resolve(self):
         if self._pending:

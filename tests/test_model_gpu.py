@@ -492,3 +492,17 @@ def test_background_resume_snapshot_on_the_gpu(tmp_path):
     assert ck.load_resume(path, fresh, (), 0) == 2
     for o, (m, v) in zip(fresh.optims, truth[2]):
         assert torch.equal(o.master, m) and torch.equal(o.exp_avg_sq, v)
+
+
+def test_phase_timer_holds_a_bounded_number_of_events():
+    """Event mode of the profiler over a long run: finished event pairs are folded into the totals as the run goes."""
+    from distributed_pytorch_amd.utils.profiling import PhaseTimer
+    t = PhaseTimer("events")
+    x = torch.ones(1024, device="cuda")
+    for _ in range(2000):
+        with t.phase("forward"):
+            x = x * 1.0001
+    assert len(t._pending) < 600 and t.cnt["forward"] == 2000
+    rep = t.report()
+    assert "forward" in rep and not t._pending
+    assert t.tot["forward"] > 0
