@@ -12,6 +12,7 @@ Reference behaviour: ``nn.Linear`` (reference: single-gpu/model.py:112-114,373-3
 """
 from __future__ import annotations
 
+import collections
 import os
 import weakref
 
@@ -234,7 +235,7 @@ def _input_grad(dy2: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 class _Deferral:
     active = False
     queue: list = []
-    log: list = []      # ("defer" | "run", n): what tests look at
+    log = collections.deque(maxlen=1024)      # ("defer" | "run", n): the most recent events, what tests look at
 
 
 def begin_deferred_wgrads() -> None:
